@@ -1,0 +1,148 @@
+/*
+ * vrt.h -- C ABI of the MI355X-native trace_rays engine (libvrt_hip.so).
+ *
+ * This is the drop-in boundary for the reference's ray-march seam.  The reference has
+ * no C ABI: its seam is the C++ class TraceRaysCu<DiffType>
+ * (/root/reference/src/cuda_volume_raytracer.h:61-115), whose object file exports
+ * exactly six symbols to the scene layer (image_util.cpp:561, 630, 752, 777).  Each
+ * entry point below names the reference interface it replaces.  INTEGRATION.md shows
+ * the C++ shim that re-creates those six symbols on top of this header, plus the
+ * pybind11 / JNI / ctypes bindings.
+ *
+ * Conventions: plain pointers and sizes only; all buffers caller-owned; functions
+ * return VRT_OK (0) or a negative vrt_status and never throw; the message of the last
+ * failure on the calling thread is available from vrt_last_error().  There is no CPU
+ * fallback: without a usable gfx950 device vrt_create fails with VRT_ERR_NO_DEVICE.
+ *
+ * Data conventions (identical to the reference seam):
+ *   positions   uint32 16.16 fixed point, 3 per ray (x,y,z), in FIELD coordinates (the
+ *               caller has already applied the -0x10000 shift, image_util.cpp:690-709)
+ *   directions  VRT_F32: float, unit 1.0;  VRT_I16: int16 8.8 fixed, unit 0x100 (types.h:41-49)
+ *   field       dim+1 = 4 channels per voxel {dx,dy,dz,w}, index ((x*By)+y)*Bz+z
+ *               (cuda_volume_raytracer.cu:111-113, 456-466)
+ */
+#ifndef VRT_H
+#define VRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VRT_ABI_VERSION 1
+
+/* element types: DiffType / DirType of the reference's template instantiations
+ * (cuda_volume_raytracer.cu:992-1049) */
+#define VRT_F32 0
+#define VRT_I16 1
+
+typedef enum vrt_status {
+    VRT_OK = 0,
+    VRT_ERR_INVALID_ARGUMENT = -1,
+    VRT_ERR_ILLEGAL_DIMENSION = -2, /* "Illegal dimension", cuda_volume_raytracer.cu:770 */
+    VRT_ERR_HIP = -3,               /* HIP runtime failure; text in vrt_last_error() (cf. HANDLE_ERROR, .cu:54-63) */
+    VRT_ERR_OUT_OF_MEMORY = -4,
+    VRT_ERR_NO_DEVICE = -5,
+    VRT_ERR_SCENE = -6,             /* scene front end rejected the input (image_util.cpp:508-516, 537-543, 605) */
+    VRT_ERR_RAY_RANGE = -7          /* "ray i: ... is not in 0 to ...", image_util.cpp:690-695 */
+} vrt_status;
+
+/* struct Options, types.h:83-91.  Zero-initialise, then call vrt_options_default(). */
+typedef struct vrt_options {
+    int32_t  loglevel;       /* _loglevel: <0 prints progress to stdout (cuda_volume_raytracer.cu:823, 948) */
+    uint64_t minimum_gpu;    /* _minimum_gpu (0x80): kept for ABI parity; this engine always runs on the GPU */
+    int32_t  write_instance; /* _write_instance: kept for ABI parity (debug record/replay is out of scope) */
+    uint64_t max_cpu;        /* _max_cpu (256): kept for ABI parity; unused (no CPU path) */
+    int32_t  device;         /* extension: HIP device ordinal, -1 = current device */
+    int32_t  kernel;         /* extension: VRT_KERNEL_* selector, 0 = auto */
+    int32_t  sort_rays;      /* extension: 0 = auto, 1 = force tile ordering, -1 = keep caller order */
+    int32_t  reserved[5];
+} vrt_options;
+
+#define VRT_KERNEL_AUTO   0
+#define VRT_KERNEL_DIRECT 1   /* one lane per ray, trilinear corners gathered straight from L1/L2 */
+#define VRT_KERNEL_SLAB   2   /* wave-cooperative LDS slab staging */
+
+typedef struct vrt_engine *vrt_handle;
+
+void vrt_options_default(vrt_options *opt);
+
+/* Number of usable HIP devices; replaces init()'s cudaGetDeviceCount (cuda_volume_raytracer.cu:82-101). */
+int vrt_device_count(void);
+
+/* ABI version of the loaded library (== VRT_ABI_VERSION). */
+int vrt_abi_version(void);
+
+/*
+ * Replaces TraceRaysCu<DiffType>::TraceRaysCu(bounds, diff, translucency_cropped)
+ * (cuda_volume_raytracer.cu:644-720): builds w = (0x7FFFFFFF - translucency)/0x10000,
+ * interleaves {diff[0..dim), w} per voxel and keeps the result resident in HBM.
+ *   dim            must be 3 (2 -> VRT_ERR_ILLEGAL_DIMENSION: the reference's 2-D
+ *                  interpolation is defective, .cu:207-208, and no config uses it)
+ *   bounds[dim]    field extents (= volume extents - 2)
+ *   field_type     VRT_F32 (diff is float*) or VRT_I16 (diff is int16_t*)
+ *   diff[dim]      HOST pointers, nvox elements each
+ *   transl_cropped HOST pointer, nvox uint32
+ */
+int vrt_create(vrt_handle *out, int dim, const uint16_t *bounds, int field_type,
+               const void *const *diff, const uint32_t *transl_cropped, size_t nvox,
+               const vrt_options *opt);
+
+/*
+ * Same engine from DEVICE-resident inputs (no reference counterpart: the reference
+ * re-uploads from host vectors, .cu:684-685).  diff[i] / transl_cropped are device
+ * pointers on the engine's device; the interleave runs on the GPU.
+ */
+int vrt_create_from_device(vrt_handle *out, int dim, const uint16_t *bounds, int field_type,
+                           const void *const *d_diff, const uint32_t *d_transl_cropped, size_t nvox,
+                           const vrt_options *opt);
+
+/*
+ * Replaces TraceRaysCu<DiffType>::trace_rays_cu<DirType>(...) (cuda_volume_raytracer.cu:722-972).
+ * All pointers are HOST pointers; the call returns when the outputs are complete.
+ *   dir_type        VRT_F32 / VRT_I16 (type of start_dir and end_dir)
+ *   start_pos       3*nrays uint32        start_dir  3*nrays
+ *   end_pos         3*nrays uint32        end_dir    3*nrays
+ *   end_iter        nrays  (= iterations - remaining, .cu:953-956)
+ *   remaining_light nrays  (always 0xFFFFFFFF: translucency is a DummyArray at every
+ *                   reference call site, .cu:882-938, 485)
+ *   path            NULL, or iterations*3*nrays uint32 laid out as the reference's
+ *                   path vector (.cu:791-794, 333-358)
+ *   invscale        3 floats
+ *   min_brightness  accepted and ignored, as in the reference (.cu:785)
+ *   iterations      per-ray step cap, must be >= 1
+ */
+int vrt_trace(vrt_handle h, int dir_type, size_t nrays,
+              const uint32_t *start_pos, const void *start_dir,
+              uint32_t *end_pos, void *end_dir, uint32_t *end_iter, uint32_t *remaining_light,
+              uint32_t *path, const float *invscale, uint32_t min_brightness,
+              uint32_t iterations, const vrt_options *opt);
+
+/*
+ * Device-pointer form of vrt_trace: every array argument is a DEVICE pointer on the
+ * engine's device (invscale stays a host pointer).  Work is enqueued on `stream`
+ * (a hipStream_t, NULL = the null stream) and the call returns without synchronising.
+ */
+int vrt_trace_device(vrt_handle h, int dir_type, size_t nrays,
+                     const uint32_t *d_start_pos, const void *d_start_dir,
+                     uint32_t *d_end_pos, void *d_end_dir, uint32_t *d_end_iter, uint32_t *d_remaining_light,
+                     uint32_t *d_path, const float *invscale, uint32_t min_brightness,
+                     uint32_t iterations, void *stream, const vrt_options *opt);
+
+/* Replaces TraceRaysCu<DiffType>::~TraceRaysCu() (cuda_volume_raytracer.cu:974-989). NULL is a no-op. */
+void vrt_destroy(vrt_handle h);
+
+/* Introspection (extension). */
+int    vrt_engine_device(vrt_handle h);             /* device ordinal the field lives on */
+size_t vrt_engine_field_bytes(vrt_handle h);        /* resident interleaved field size */
+const void *vrt_engine_field_device_ptr(vrt_handle h);
+
+/* Message of the last failure on this thread ("" if none).  Valid until the next failing call. */
+const char *vrt_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VRT_H */

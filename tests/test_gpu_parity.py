@@ -1,0 +1,217 @@
+"""GPU (-m gpu): the HIP engine, called through the C ABI (include/vrt.h), against
+  (a) the golden vectors produced by the real reference (tests/golden/*.npz), and
+  (b) the oracle (oracle/vrt_oracle.c) on seeded inputs at sizes it finishes in seconds,
+  (c) size-independent properties at BASELINE config sizes.
+Bar: bit-exact (positions/iterations are integers; directions are fp32 computed with the
+reference CPU build's operation order -- stronger than the 1e-5 relative tolerance north_star allows).
+Nothing here reads /root/reference."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from volumeraytracer_amd import capi, workloads as W
+
+pytestmark = pytest.mark.gpu
+KEYS = ("end_position", "end_direction", "end_iteration", "remaining_light")
+KERNELS = [capi.KERNEL_DIRECT, capi.KERNEL_SLAB]
+
+
+def _same(a, b):
+    return a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+def _assert_same(got, want, keys=KEYS, ctx=""):
+    for k in keys:
+        if not _same(got[k], want[k]):
+            bad = np.flatnonzero(got[k].reshape(-1) != want[k].reshape(-1))
+            raise AssertionError("%s %s: %d of %d differ, first at %d: got %r want %r" % (
+                ctx, k, bad.size, got[k].size, bad[0], got[k].reshape(-1)[bad[0]], want[k].reshape(-1)[bad[0]]))
+
+
+def _opts(kernel, sort=0):
+    return capi.default_options(kernel=kernel, sort_rays=sort)
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def test_device_present():
+    assert capi.device_count() >= 1, "no HIP device: the GPU tests must not pass vacuously"
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("ftag", ["f32", "i16"])
+@pytest.mark.parametrize("dtag", ["f32", "i16"])
+def test_golden_seam(golden_dir, ftag, dtag, kernel):
+    g = _load(golden_dir, "F2_seam_%s_%s" % (ftag, dtag))
+    with capi.Engine.from_host(g["bounds"], [g["dx"], g["dy"], g["dz"]], g["transl_cropped"]) as eng:
+        for sort in (-1, 1):
+            for j in range(3):
+                got = eng.trace(g["start_position"], g["start_direction"], g["invscale%d" % j], 100000,
+                                options=_opts(kernel, sort))
+                _assert_same(got, {k: g["%s_%d" % (k, j)] for k in KEYS}, ctx="inv%d sort%d" % (j, sort))
+            for cap in (1, 2, 3, 17):
+                got = eng.trace(g["start_position"], g["start_direction"], [1, 1, 1], cap, options=_opts(kernel, sort))
+                _assert_same(got, {k: g["%s_cap%d" % (k, cap)] for k in KEYS}, ctx="cap%d" % cap)
+        got = eng.trace(g["start_position"][:96], g["start_direction"][:96], [1, 1, 1], 48, trace_paths=True,
+                        options=_opts(kernel))
+        _assert_same(got, {k: g[k + "_path48"] for k in KEYS + ("path",)}, keys=KEYS + ("path",), ctx="path")
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("ftag", ["f32", "i16"])
+def test_golden_opaque(golden_dir, ftag, kernel):
+    g = _load(golden_dir, "F3_opaque_" + ftag)
+    with capi.Engine.from_host(g["bounds"], [g["dx"], g["dy"], g["dz"]], g["transl_cropped"]) as eng:
+        got = eng.trace(g["start_position"], g["start_direction"], g["invscale"], int(g["iterations"]),
+                        options=_opts(kernel))
+        _assert_same(got, g)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("tag", ["f32", "i16"])
+def test_golden_scaling_seam(golden_dir, tag, kernel):
+    """The reference's scaling_test (46718 +- 100 steps): scene build + ray front end by the
+    oracle (host-side rows, SURVEY f-1/f-2), the march itself on the GPU."""
+    g = _load(golden_dir, "F1_scaling_" + tag)
+    dx, dy, dz, tc, ob = oracle.port.scene_build(g["bounds"], g["ior"], g["translucency"])
+    pos, d = oracle.port.ray_prologue(g["bounds"], g["ior"], g["start_position"], g["start_direction"])
+    with capi.Engine.from_host(ob, [dx, dy, dz], tc) as eng:
+        got = eng.trace(pos, d, g["invscale"], int(g["iterations"]), options=_opts(kernel))
+    got["end_position"] = got["end_position"] + np.uint32(0x10000)
+    _assert_same(got, g)
+    assert abs(int(got["end_iteration"][0]) - 46718) <= 100 and abs(int(got["end_iteration"][1]) - 46718) <= 100
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("fdt", [np.float32, np.int16])
+@pytest.mark.parametrize("ddt", [np.float32, np.int16])
+def test_vs_oracle_coherent(fdt, ddt, kernel):
+    """Coherent bundles (the bench's ray generators) at a size the oracle does in seconds."""
+    N = 72
+    bounds, dx, dy, dz, tc = W.seam_field(N, fdt, opaque_radius=6.0)
+    field = oracle.port.interleave(dx, dy, dz, tc)
+    with capi.Engine.from_host(bounds, [dx, dy, dz], tc) as eng:
+        for gen, R in ((W.ortho_rays, 150), (W.perspective_rays, 131)):
+            sp, sd = gen(N, R, dir_dtype=ddt)
+            for inv in ([1, 1, 1], [2, 2, 2]):
+                want = oracle.port.trace(field, bounds, sp, sd, inv, 100000)
+                got = eng.trace(sp, sd, inv, 100000, options=_opts(kernel))
+                _assert_same(got, want, ctx="%s inv=%s" % (gen.__name__, inv))
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_vs_oracle_incoherent(kernel):
+    """Random starts and directions: every wavefront is incoherent (slab kernel's global-gather fallback)."""
+    N = 40
+    bounds, dx, dy, dz, tc = W.seam_field(N, np.float32, seed=3, opaque_radius=4.0)
+    field = oracle.port.interleave(dx, dy, dz, tc)
+    sp, sd = W.random_rays(N, 5000, seed=17, vol_seed=3)
+    want = oracle.port.trace(field, bounds, sp, sd, [1, 1, 1], 100000)
+    with capi.Engine.from_host(bounds, [dx, dy, dz], tc) as eng:
+        for sort in (-1, 1):
+            got = eng.trace(sp, sd, [1, 1, 1], 100000, options=_opts(kernel, sort))
+            _assert_same(got, want, ctx="sort%d" % sort)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_edge_cases(kernel):
+    N = 20
+    bounds, dx, dy, dz, tc = W.seam_field(N, np.float32)
+    field = oracle.port.interleave(dx, dy, dz, tc)
+    with capi.Engine.from_host(bounds, [dx, dy, dz], tc) as eng:
+        # empty ray set
+        got = eng.trace(np.zeros(0, np.uint32), np.zeros(0, np.float32), [1, 1, 1], 10, options=_opts(kernel))
+        assert got["end_iteration"].size == 0
+        # ragged counts (not a multiple of the 64-lane wavefront / 256-thread block)
+        for n in (1, 63, 65, 257):
+            sp, sd = W.random_rays(N, n, seed=n)
+            want = oracle.port.trace(field, bounds, sp, sd, [1, 1, 1], 1000)
+            _assert_same(eng.trace(sp, sd, [1, 1, 1], 1000, options=_opts(kernel)), want, ctx="n=%d" % n)
+        # rays that start outside the field, on the last valid cell, and with zero direction
+        B = bounds[0]
+        sp = np.array([0xFFFF0000, 0x20000, 0x20000,
+                       (B - 2) * 0x10000 + 0xFFFF, (B - 2) * 0x10000 + 0xFFFF, (B - 2) * 0x10000 + 0xFFFF,
+                       (B - 1) * 0x10000, 0x20000, 0x20000,
+                       0x28000, 0x28000, 0x28000], np.uint32)
+        sd = np.array([1, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0], np.float32)
+        want = oracle.port.trace(field, bounds, sp, sd, [1, 1, 1], 50)
+        _assert_same(eng.trace(sp, sd, [1, 1, 1], 50, options=_opts(kernel)), want, ctx="edges")
+        # iterations == 0 is rejected, never executed
+        with pytest.raises(capi.VrtError):
+            eng.trace(sp, sd, [1, 1, 1], 0, options=_opts(kernel))
+
+
+def test_path_chunking_and_caps():
+    """Path tracing in several device chunks (budget-bounded), iteration cap hit by every ray."""
+    N = 24
+    bounds, dx, dy, dz, tc = W.seam_field(N, np.int16)
+    field = oracle.port.interleave(dx, dy, dz, tc)
+    sp, sd = W.ortho_rays(N, 40, dir_dtype=np.int16)
+    want = oracle.port.trace(field, bounds, sp, sd, [1, 1, 1], 30, trace_paths=True)
+    with capi.Engine.from_host(bounds, [dx, dy, dz], tc) as eng:
+        got = eng.trace(sp, sd, [1, 1, 1], 30, trace_paths=True)
+    _assert_same(got, want, keys=KEYS + ("path",))
+    assert np.all(got["end_iteration"] == 30)
+
+
+def test_create_from_device_and_trace_device():
+    """Device-pointer entry points (what bench.py times): same bits as the host path."""
+    torch = pytest.importorskip("torch")
+    N = 64
+    bounds, dx, dy, dz, tc = W.seam_field(N, np.float32)
+    field = oracle.port.interleave(dx, dy, dz, tc)
+    sp, sd = W.perspective_rays(N, 128)
+    want = oracle.port.trace(field, bounds, sp, sd, [1, 1, 1], 100000)
+    dev = torch.device("cuda:0")
+    t = [torch.from_numpy(a).to(dev) for a in (dx, dy, dz)]
+    ttc = torch.from_numpy(tc.view(np.int32)).to(dev)
+    n = sp.size // 3
+    eng = capi.Engine.from_device(bounds, [x.data_ptr() for x in t], ttc.data_ptr(), capi.VRT_F32, dx.size)
+    dsp = torch.from_numpy(sp.view(np.int32)).to(dev)
+    dsd = torch.from_numpy(sd).to(dev)
+    ep = torch.empty(3 * n, dtype=torch.int32, device=dev)
+    ed = torch.empty(3 * n, dtype=torch.float32, device=dev)
+    ei = torch.empty(n, dtype=torch.int32, device=dev)
+    rl = torch.empty(n, dtype=torch.int32, device=dev)
+    for kernel in KERNELS:
+        eng.trace_device(capi.VRT_F32, n, dsp.data_ptr(), dsd.data_ptr(), ep.data_ptr(), ed.data_ptr(), ei.data_ptr(),
+                         rl.data_ptr(), [1, 1, 1], 100000, stream=torch.cuda.current_stream().cuda_stream,
+                         options=_opts(kernel))
+        torch.cuda.synchronize()
+        got = dict(end_position=ep.cpu().numpy().view(np.uint32), end_direction=ed.cpu().numpy(),
+                   end_iteration=ei.cpu().numpy().view(np.uint32), remaining_light=rl.cpu().numpy().view(np.uint32))
+        _assert_same(got, want, ctx="kernel %d" % kernel)
+    eng.close()
+
+
+def test_config2_properties():
+    """BASELINE config 2 size (256^3 fp32, 512x512 perspective): both kernels agree bit-for-bit
+    with each other on every ray and with the oracle on a strided sample; ordering invariance."""
+    N, R = 256, 512
+    bounds, dx, dy, dz, tc = W.seam_field(N, np.float32)
+    sp, sd = W.perspective_rays(N, R)
+    with capi.Engine.from_host(bounds, [dx, dy, dz], tc) as eng:
+        a = eng.trace(sp, sd, [1, 1, 1], 100000, options=_opts(capi.KERNEL_DIRECT, -1))
+        b = eng.trace(sp, sd, [1, 1, 1], 100000, options=_opts(capi.KERNEL_SLAB, 1))
+        _assert_same(a, b, ctx="direct vs slab")
+        # permutation invariance: a shuffled ray order gives the same per-ray results
+        perm = np.random.RandomState(0).permutation(R * R)
+        c = eng.trace(sp.reshape(-1, 3)[perm].reshape(-1), sd.reshape(-1, 3)[perm].reshape(-1), [1, 1, 1], 100000,
+                      options=_opts(capi.KERNEL_SLAB, 0))
+        assert np.array_equal(c["end_position"].reshape(-1, 3), b["end_position"].reshape(-1, 3)[perm])
+        assert np.array_equal(c["end_iteration"], b["end_iteration"][perm])
+    field = oracle.port.interleave(dx, dy, dz, tc)
+    idx = np.arange(0, R * R, 97)
+    want = oracle.port.trace(field, bounds, sp.reshape(-1, 3)[idx].reshape(-1), sd.reshape(-1, 3)[idx].reshape(-1),
+                             [1, 1, 1], 100000)
+    assert np.array_equal(want["end_position"].reshape(-1, 3), b["end_position"].reshape(-1, 3)[idx])
+    assert np.array_equal(want["end_direction"].reshape(-1, 3).view(np.uint32),
+                          b["end_direction"].reshape(-1, 3)[idx].view(np.uint32))
+    assert np.array_equal(want["end_iteration"], b["end_iteration"][idx])
+    # all rays of this transparent scene leave the field: physical invariant |dir| == ior at exit (ior -> 1)
+    steps = b["end_iteration"].astype(np.int64)
+    assert steps.min() > 100 and steps.max() < 100000

@@ -1,0 +1,213 @@
+"""ctypes binding of the C ABI in include/vrt.h (libvrt_hip.so).
+
+This is the *only* compute path of the package: if the HIP library is missing or no
+gfx950 device is usable, calls raise -- there is no CPU fallback (and nothing here
+imports oracle/).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+VRT_F32, VRT_I16 = 0, 1
+KERNEL_AUTO, KERNEL_DIRECT, KERNEL_SLAB = 0, 1, 2
+
+# every symbol include/vrt.h declares (checked by tests/test_abi.py against the header text)
+ABI_SYMBOLS = (
+    "vrt_options_default", "vrt_device_count", "vrt_abi_version", "vrt_create", "vrt_create_from_device",
+    "vrt_trace", "vrt_trace_device", "vrt_destroy", "vrt_engine_device", "vrt_engine_field_bytes",
+    "vrt_engine_field_device_ptr", "vrt_last_error",
+)
+
+
+class VrtError(RuntimeError):
+    """A C-ABI call returned a negative vrt_status (message from vrt_last_error())."""
+
+    def __init__(self, code, msg):
+        super().__init__("%s (vrt_status %d)" % (msg, code))
+        self.code = code
+
+
+class Options(C.Structure):
+    """struct vrt_options == the reference's struct Options (types.h:83-91) + extensions."""
+    _fields_ = [("loglevel", C.c_int32), ("minimum_gpu", C.c_uint64), ("write_instance", C.c_int32),
+                ("max_cpu", C.c_uint64), ("device", C.c_int32), ("kernel", C.c_int32),
+                ("sort_rays", C.c_int32), ("reserved", C.c_int32 * 5)]
+
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """Load libvrt_hip.so (never builds implicitly on import of the package; raises if absent)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError("libvrt_hip.so not built: run `python -m volumeraytracer_amd._build` "
+                          "(or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(path)
+    vp, u32p, sz = C.c_void_p, C.c_void_p, C.c_size_t
+    L.vrt_options_default.argtypes = [C.POINTER(Options)]
+    L.vrt_options_default.restype = None
+    L.vrt_device_count.restype = C.c_int
+    L.vrt_abi_version.restype = C.c_int
+    L.vrt_last_error.restype = C.c_char_p
+    L.vrt_create.argtypes = [C.POINTER(vp), C.c_int, vp, C.c_int, C.POINTER(vp), u32p, sz, C.POINTER(Options)]
+    L.vrt_create_from_device.argtypes = L.vrt_create.argtypes
+    L.vrt_trace.argtypes = [vp, C.c_int, sz, u32p, vp, u32p, vp, u32p, u32p, u32p, vp, C.c_uint32, C.c_uint32,
+                            C.POINTER(Options)]
+    L.vrt_trace_device.argtypes = [vp, C.c_int, sz, u32p, vp, u32p, vp, u32p, u32p, u32p, vp, C.c_uint32,
+                                   C.c_uint32, vp, C.POINTER(Options)]
+    L.vrt_destroy.argtypes = [vp]
+    L.vrt_destroy.restype = None
+    L.vrt_engine_device.argtypes = [vp]
+    L.vrt_engine_field_bytes.argtypes = [vp]
+    L.vrt_engine_field_bytes.restype = sz
+    L.vrt_engine_field_device_ptr.argtypes = [vp]
+    L.vrt_engine_field_device_ptr.restype = vp
+    if hasattr(L, "vrt_scene_create"):
+        L.vrt_scene_create.argtypes = [C.POINTER(vp), C.c_int, vp, C.c_int, vp, u32p, sz, C.POINTER(Options)]
+        L.vrt_scene_trace.argtypes = [vp, C.c_int, sz, u32p, vp, u32p, vp, u32p, u32p, u32p, vp, C.c_uint32,
+                                      C.c_uint32, C.c_int, C.POINTER(Options)]
+        L.vrt_scene_destroy.argtypes = [vp]
+        L.vrt_scene_destroy.restype = None
+        L.vrt_scene_engine.argtypes = [vp]
+        L.vrt_scene_engine.restype = vp
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise VrtError(rc, load().vrt_last_error().decode(errors="replace"))
+
+
+def default_options(**kw):
+    o = Options()
+    load().vrt_options_default(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def device_count():
+    return int(load().vrt_device_count())
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _type_of(dt):
+    dt = np.dtype(dt)
+    if dt == np.float32:
+        return VRT_F32
+    if dt == np.int16:
+        return VRT_I16
+    raise TypeError("expected float32 or int16, got %s" % dt)
+
+
+class Engine:
+    """Owning handle on a vrt_engine (a field resident in HBM on one device)."""
+
+    def __init__(self, handle, field_type, bounds):
+        self._h = handle
+        self.field_type = field_type
+        self.bounds = [int(b) for b in bounds]
+
+    @classmethod
+    def from_host(cls, bounds, diff, transl_cropped, options=None):
+        """vrt_create: diff = 3 host arrays (float32 or int16), transl_cropped uint32."""
+        L = load()
+        ft = _type_of(diff[0].dtype)
+        d = [np.ascontiguousarray(x, dtype=diff[0].dtype).reshape(-1) for x in diff]
+        tr = np.ascontiguousarray(transl_cropped, dtype=np.uint32).reshape(-1)
+        b = np.ascontiguousarray(bounds, dtype=np.uint16)
+        if len(b) != len(d):
+            raise VrtError(-2, "Illegal dimension")
+        ptrs = (C.c_void_p * len(d))(*[x.ctypes.data for x in d])
+        h = C.c_void_p()
+        check(L.vrt_create(C.byref(h), len(b), _np_ptr(b), ft, ptrs, _np_ptr(tr), d[0].size,
+                           C.byref(options) if options is not None else None))
+        return cls(h, ft, b)
+
+    @classmethod
+    def from_device(cls, bounds, diff_ptrs, transl_ptr, field_type, nvox, options=None):
+        """vrt_create_from_device: raw device pointers (ints)."""
+        L = load()
+        b = np.ascontiguousarray(bounds, dtype=np.uint16)
+        ptrs = (C.c_void_p * len(diff_ptrs))(*[int(p) for p in diff_ptrs])
+        h = C.c_void_p()
+        check(L.vrt_create_from_device(C.byref(h), len(b), _np_ptr(b), field_type, ptrs, C.c_void_p(int(transl_ptr)),
+                                       int(nvox), C.byref(options) if options is not None else None))
+        return cls(h, field_type, b)
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def device(self):
+        return int(load().vrt_engine_device(self._h))
+
+    @property
+    def field_bytes(self):
+        return int(load().vrt_engine_field_bytes(self._h))
+
+    def trace(self, start_pos, start_dir, invscale, iterations, trace_paths=False, min_brightness=0, options=None):
+        """vrt_trace on host numpy arrays; returns dict of numpy outputs."""
+        L = load()
+        sd = np.ascontiguousarray(start_dir).reshape(-1)
+        dt = _type_of(sd.dtype)
+        sp = np.ascontiguousarray(start_pos, dtype=np.uint32).reshape(-1)
+        if sp.size != sd.size or sp.size % 3:
+            raise VrtError(-1, "raycounts doesn't match, dimension is: 3 raysizes are start_position: %d "
+                               "start_direction: %d" % (sp.size, sd.size))
+        n = sp.size // 3
+        inv = np.ascontiguousarray(invscale, dtype=np.float32)
+        ep = np.empty(3 * n, np.uint32)
+        ed = np.empty(3 * n, sd.dtype)
+        ei = np.empty(n, np.uint32)
+        rl = np.empty(n, np.uint32)
+        path = np.empty(int(iterations) * 3 * n, np.uint32) if trace_paths else None
+        check(L.vrt_trace(self._h, dt, n, _np_ptr(sp), _np_ptr(sd), _np_ptr(ep), _np_ptr(ed), _np_ptr(ei),
+                          _np_ptr(rl), _np_ptr(path) if path is not None else None, _np_ptr(inv),
+                          int(min_brightness), int(iterations), C.byref(options) if options is not None else None))
+        return dict(end_position=ep, end_direction=ed, end_iteration=ei, remaining_light=rl, path=path)
+
+    def trace_device(self, dir_type, nrays, d_start_pos, d_start_dir, d_end_pos, d_end_dir, d_end_iter,
+                     d_remaining_light, invscale, iterations, d_path=0, stream=0, min_brightness=0, options=None):
+        """vrt_trace_device on raw device pointers (ints); asynchronous on `stream`."""
+        L = load()
+        inv = np.ascontiguousarray(invscale, dtype=np.float32)
+        check(L.vrt_trace_device(self._h, dir_type, int(nrays), C.c_void_p(int(d_start_pos)),
+                                 C.c_void_p(int(d_start_dir)), C.c_void_p(int(d_end_pos)), C.c_void_p(int(d_end_dir)),
+                                 C.c_void_p(int(d_end_iter)), C.c_void_p(int(d_remaining_light)),
+                                 C.c_void_p(int(d_path)) if d_path else None, _np_ptr(inv), int(min_brightness),
+                                 int(iterations), C.c_void_p(int(stream)) if stream else None,
+                                 C.byref(options) if options is not None else None))
+
+    def close(self):
+        if self._h is not None and _lib is not None:
+            _lib.vrt_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

@@ -1,0 +1,442 @@
+// vrt_engine.hip -- host runtime + C ABI (include/vrt.h) of the MI355X trace_rays engine.
+//
+// Replaces the reference's engine object / dispatcher
+//   TraceRaysCu ctor / trace_rays_cu / dtor   /root/reference/src/cuda_volume_raytracer.cu:644-989
+// The reference AoS-packs rays on the host, cuts them into 0x8000-ray chunks and runs one
+// blocking launch per chunk (.cu:797-946).  Here the field is interleaved on the device once,
+// rays stay in the caller's SoA arrays, and one launch covers all rays of a call.
+//
+// There is deliberately no CPU fallback in this file: without a HIP device every entry
+// point fails with VRT_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/vrt.h"
+#include "vrt_march.h"
+#include "vrt_slab.h"
+#include "vrt_sort.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? VRT_ERR_OUT_OF_MEMORY : VRT_ERR_HIP,           \
+                        "%s in %s at line %d (%d)", hipGetErrorString(e_), __FILE__, __LINE__, (int)e_); \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess) { ok = (prev == dev) || hipSetDevice(dev) == hipSuccess; }
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+// grow-only device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct vrt_engine {
+    int device = 0;
+    int field_type = VRT_F32;
+    uint32_t B[3] = {0, 0, 0};
+    size_t nvox = 0;
+    void *field = nullptr;         // interleaved AoS field, resident for the engine's lifetime
+    size_t field_bytes = 0;
+    hipStream_t stream = nullptr;  // used by the host-pointer entry point
+    int num_cu = 256;
+    // workspaces (grow-only; no allocation in steady state)
+    DevBuf sort_keys, sort_keys_alt, sort_vals, sort_vals_alt, sort_tmp;
+    DevBuf h_in_pos, h_in_dir, h_out_pos, h_out_dir, h_out_iter, h_out_light, h_path;
+    vrt_options opt;
+};
+
+namespace {
+
+// ---- field build: TraceRaysCu ctor, cuda_volume_raytracer.cu:654-669 ------------------------
+
+__device__ __forceinline__ int32_t w_channel(uint32_t tr)
+{
+    // (int64)0x7FFFFFFF - (int64)tr always fits int32; C++ '/' truncates like the reference's
+    return (int32_t)(0x7FFFFFFFu - tr) / 0x10000;
+}
+
+__global__ __launch_bounds__(256) void k_interleave_f32(const float *dx, const float *dy, const float *dz,
+                                                        const uint32_t *tr, vrt::vox_f32 *out, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        vrt::vox_f32 v;
+        v.c[0] = dx[i]; v.c[1] = dy[i]; v.c[2] = dz[i]; v.c[3] = (float)w_channel(tr[i]);
+        out[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_interleave_i16(const int16_t *dx, const int16_t *dy, const int16_t *dz,
+                                                        const uint32_t *tr, vrt::vox_i16 *out, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        vrt::vox_i16 v;
+        v.c[0] = dx[i]; v.c[1] = dy[i]; v.c[2] = dz[i]; v.c[3] = (int16_t)w_channel(tr[i]);
+        out[i] = v;
+    }
+}
+
+int launch_interleave(vrt_engine *e, const void *const d_diff[3], const uint32_t *d_tr, size_t off, size_t n,
+                      hipStream_t s)
+{
+    const int grid = (int)std::min<size_t>((n + 255) / 256, (size_t)e->num_cu * 8);
+    if (e->field_type == VRT_F32)
+        k_interleave_f32<<<grid, 256, 0, s>>>((const float *)d_diff[0], (const float *)d_diff[1],
+                                               (const float *)d_diff[2], d_tr, (vrt::vox_f32 *)e->field + off, n);
+    else
+        k_interleave_i16<<<grid, 256, 0, s>>>((const int16_t *)d_diff[0], (const int16_t *)d_diff[1],
+                                               (const int16_t *)d_diff[2], d_tr, (vrt::vox_i16 *)e->field + off, n);
+    HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+
+int check_create_args(vrt_handle *out, int dim, const uint16_t *bounds, int field_type, const void *const *diff,
+                      const uint32_t *tr, size_t nvox)
+{
+    if (!out) return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_create: out is NULL");
+    *out = nullptr;
+    if (dim != 3) return fail(VRT_ERR_ILLEGAL_DIMENSION, "Illegal dimension: %d (only 3-D fields are supported)", dim);
+    if (!bounds || !diff || !tr) return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_create: NULL argument");
+    if (field_type != VRT_F32 && field_type != VRT_I16)
+        return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_create: unknown field_type %d", field_type);
+    for (int d = 0; d < 3; ++d) {
+        if (!diff[d]) return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_create: diff[%d] is NULL", d);
+        if (bounds[d] == 0) return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_create: bounds[%d] is zero", d);
+    }
+    if ((size_t)bounds[0] * bounds[1] * bounds[2] != nvox)
+        return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_create: nvox %zu != product of bounds %zu", nvox,
+                    (size_t)bounds[0] * bounds[1] * bounds[2]);
+    return VRT_OK;
+}
+
+int engine_alloc(vrt_engine **pe, const uint16_t *bounds, int field_type, size_t nvox, const vrt_options *opt)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(VRT_ERR_NO_DEVICE, "no HIP device available (this engine has no CPU path)");
+    vrt_engine *e = new (std::nothrow) vrt_engine();
+    if (!e) return fail(VRT_ERR_OUT_OF_MEMORY, "host allocation failed");
+    if (opt) e->opt = *opt; else vrt_options_default(&e->opt);
+    int dev = e->opt.device;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev >= ndev) { delete e; return fail(VRT_ERR_INVALID_ARGUMENT, "device %d out of range (%d devices)", dev, ndev); }
+    e->device = dev;
+    e->field_type = field_type;
+    for (int d = 0; d < 3; ++d) e->B[d] = bounds[d];
+    e->nvox = nvox;
+    e->field_bytes = nvox * (field_type == VRT_F32 ? 16 : 8);
+    *pe = e;
+    return VRT_OK;
+}
+
+int engine_init_device(vrt_engine *e)
+{
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, e->device));
+    e->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    // +64 bytes of zeroed tail so that a 16-byte pair load at the very last voxel stays inside
+    // the allocation (the march never reads it: the loop requires pos>>16 < bounds-1).
+    HIP_TRY(hipMalloc(&e->field, e->field_bytes + 64));
+    HIP_TRY(hipMemsetAsync((char *)e->field + e->field_bytes, 0, 64, e->stream));
+    return VRT_OK;
+}
+
+void engine_free(vrt_engine *e)
+{
+    if (!e) return;
+    DeviceGuard g(e->device);
+    if (e->stream) { (void)hipStreamSynchronize(e->stream); (void)hipStreamDestroy(e->stream); }
+    if (e->field) (void)hipFree(e->field);
+    DevBuf *bufs[] = {&e->sort_keys, &e->sort_keys_alt, &e->sort_vals, &e->sort_vals_alt, &e->sort_tmp,
+                      &e->h_in_pos, &e->h_in_dir, &e->h_out_pos, &e->h_out_dir, &e->h_out_iter, &e->h_out_light,
+                      &e->h_path};
+    for (DevBuf *b : bufs) b->release();
+    delete e;
+}
+
+// ---- launch ---------------------------------------------------------------------------------
+
+template <typename FieldT, typename DirT>
+int launch_typed(vrt_engine *e, const vrt::MarchParams &p, int kernel, hipStream_t s)
+{
+    const bool path = p.path != nullptr;
+    if (kernel == VRT_KERNEL_SLAB) {
+        return vrt::launch_slab<FieldT, DirT>(p, path, e->num_cu, s) == hipSuccess
+                   ? VRT_OK : fail(VRT_ERR_HIP, "slab kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    const unsigned grid = (p.nrays + 255) / 256;
+    if (path) vrt::k_march_direct<FieldT, DirT, true><<<grid, 256, 0, s>>>(p);
+    else      vrt::k_march_direct<FieldT, DirT, false><<<grid, 256, 0, s>>>(p);
+    HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+
+int trace_device_impl(vrt_engine *e, int dir_type, size_t nrays, const uint32_t *d_sp, const void *d_sd,
+                      uint32_t *d_ep, void *d_ed, uint32_t *d_ei, uint32_t *d_rl, uint32_t *d_path,
+                      const float *invscale, uint32_t iterations, hipStream_t s, const vrt_options *opt)
+{
+    if (nrays == 0) return VRT_OK;
+    const vrt_options &o = opt ? *opt : e->opt;
+    vrt::MarchParams p;
+    p.field = e->field;
+    p.Bx = e->B[0]; p.By = e->B[1]; p.Bz = e->B[2];
+    p.invx = invscale[0]; p.invy = invscale[1]; p.invz = invscale[2];
+    p.start_pos = d_sp; p.start_dir = d_sd;
+    p.end_pos = d_ep; p.end_dir = d_ed; p.end_iter = d_ei; p.remaining_light = d_rl;
+    p.path = d_path;
+    p.order = nullptr;
+    p.iterations = iterations;
+    p.nrays = (uint32_t)nrays;
+    p.slab_lds_bytes = 0;
+
+    int kernel = o.kernel;
+    if (kernel == VRT_KERNEL_AUTO) kernel = d_path ? VRT_KERNEL_DIRECT : VRT_KERNEL_SLAB;
+    if (kernel != VRT_KERNEL_DIRECT && kernel != VRT_KERNEL_SLAB)
+        return fail(VRT_ERR_INVALID_ARGUMENT, "unknown kernel selector %d", kernel);
+    if (kernel == VRT_KERNEL_SLAB && d_path) kernel = VRT_KERNEL_DIRECT;   // path tracing is write-bound: direct kernel
+
+    // tile ordering: group rays that enter the field close together into the same wavefront
+    const bool sort = o.sort_rays > 0 || (o.sort_rays == 0 && nrays >= 4096);
+    if (sort) {
+        const uint32_t *order = nullptr;
+        hipError_t se = vrt::build_tile_order(d_sp, d_sd, dir_type, (uint32_t)nrays, e->sort_keys, e->sort_keys_alt,
+                                              e->sort_vals, e->sort_vals_alt, e->sort_tmp, s, &order);
+        if (se != hipSuccess) return fail(se == hipErrorOutOfMemory ? VRT_ERR_OUT_OF_MEMORY : VRT_ERR_HIP,
+                                          "ray tile ordering failed: %s", hipGetErrorString(se));
+        p.order = order;
+    }
+
+    if (e->field_type == VRT_F32) {
+        if (dir_type == VRT_F32) return launch_typed<float, float>(e, p, kernel, s);
+        return launch_typed<float, int16_t>(e, p, kernel, s);
+    }
+    if (dir_type == VRT_F32) return launch_typed<int16_t, float>(e, p, kernel, s);
+    return launch_typed<int16_t, int16_t>(e, p, kernel, s);
+}
+
+int check_trace_args(vrt_handle h, int dir_type, size_t nrays, const void *sp, const void *sd, const void *ep,
+                     const void *ed, const void *ei, const void *rl, const float *invscale, uint32_t iterations)
+{
+    if (!h) return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_trace: NULL handle");
+    if (dir_type != VRT_F32 && dir_type != VRT_I16)
+        return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_trace: unknown dir_type %d", dir_type);
+    if (!invscale) return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_trace: invscale is NULL");
+    if (iterations == 0)
+        return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_trace: iterations must be >= 1 (the reference underflows at 0, "
+                                              "cuda_volume_raytracer.cu:333)");
+    if (nrays > 0xFFFFFFF0u) return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_trace: too many rays (%zu)", nrays);
+    if (nrays && (!sp || !sd || !ep || !ed || !ei || !rl))
+        return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_trace: NULL ray array");
+    return VRT_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+
+extern "C" {
+
+void vrt_options_default(vrt_options *opt)
+{
+    if (!opt) return;
+    memset(opt, 0, sizeof *opt);
+    opt->loglevel = 0;
+    opt->minimum_gpu = 0x80;       // types.h:90
+    opt->write_instance = 0;
+    opt->max_cpu = 256;
+    opt->device = -1;
+    opt->kernel = VRT_KERNEL_AUTO;
+    opt->sort_rays = 0;
+}
+
+int vrt_abi_version(void) { return VRT_ABI_VERSION; }
+
+int vrt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *vrt_last_error(void) { return g_err.c_str(); }
+
+int vrt_create_from_device(vrt_handle *out, int dim, const uint16_t *bounds, int field_type,
+                           const void *const *d_diff, const uint32_t *d_tr, size_t nvox, const vrt_options *opt)
+{
+    int rc = check_create_args(out, dim, bounds, field_type, d_diff, d_tr, nvox);
+    if (rc) return rc;
+    vrt_engine *e = nullptr;
+    rc = engine_alloc(&e, bounds, field_type, nvox, opt);
+    if (rc) return rc;
+    DeviceGuard g(e->device);
+    rc = engine_init_device(e);
+    if (!rc) rc = launch_interleave(e, d_diff, d_tr, 0, nvox, e->stream);
+    if (!rc && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail(VRT_ERR_HIP, "field interleave failed");
+    if (rc) { engine_free(e); return rc; }
+    *out = e;
+    return VRT_OK;
+}
+
+int vrt_create(vrt_handle *out, int dim, const uint16_t *bounds, int field_type, const void *const *diff,
+               const uint32_t *tr, size_t nvox, const vrt_options *opt)
+{
+    int rc = check_create_args(out, dim, bounds, field_type, diff, tr, nvox);
+    if (rc) return rc;
+    vrt_engine *e = nullptr;
+    rc = engine_alloc(&e, bounds, field_type, nvox, opt);
+    if (rc) return rc;
+    DeviceGuard g(e->device);
+    rc = engine_init_device(e);
+    if (rc) { engine_free(e); return rc; }
+
+    // Upload + interleave in bounded chunks (the reference interleaves serially on the host and
+    // uploads the 4-channel copy, .cu:660-685; here the host arrays are uploaded as they are and
+    // interleaved on the device).
+    const size_t esz = field_type == VRT_F32 ? 4 : 2;
+    const size_t chunk = std::min<size_t>(nvox, (size_t)32 << 20);
+    DevBuf tmp[4];
+    auto cleanup = [&](int code) { for (DevBuf &b : tmp) b.release(); engine_free(e); return code; };
+    for (int k = 0; k < 3; ++k)
+        if (tmp[k].reserve(chunk * esz) != hipSuccess) return cleanup(fail(VRT_ERR_OUT_OF_MEMORY, "device allocation failed"));
+    if (tmp[3].reserve(chunk * 4) != hipSuccess) return cleanup(fail(VRT_ERR_OUT_OF_MEMORY, "device allocation failed"));
+    for (size_t off = 0; off < nvox; off += chunk) {
+        const size_t n = std::min(chunk, nvox - off);
+        for (int k = 0; k < 3; ++k)
+            if (hipMemcpyAsync(tmp[k].p, (const char *)diff[k] + off * esz, n * esz, hipMemcpyHostToDevice, e->stream) != hipSuccess)
+                return cleanup(fail(VRT_ERR_HIP, "field upload failed"));
+        if (hipMemcpyAsync(tmp[3].p, tr + off, n * 4, hipMemcpyHostToDevice, e->stream) != hipSuccess)
+            return cleanup(fail(VRT_ERR_HIP, "field upload failed"));
+        const void *d[3] = {tmp[0].p, tmp[1].p, tmp[2].p};
+        rc = launch_interleave(e, d, (const uint32_t *)tmp[3].p, off, n, e->stream);
+        if (rc) return cleanup(rc);
+        if (hipStreamSynchronize(e->stream) != hipSuccess) return cleanup(fail(VRT_ERR_HIP, "field interleave failed"));
+    }
+    for (DevBuf &b : tmp) b.release();
+    *out = e;
+    return VRT_OK;
+}
+
+int vrt_trace_device(vrt_handle h, int dir_type, size_t nrays, const uint32_t *d_sp, const void *d_sd,
+                     uint32_t *d_ep, void *d_ed, uint32_t *d_ei, uint32_t *d_rl, uint32_t *d_path,
+                     const float *invscale, uint32_t /*min_brightness*/, uint32_t iterations, void *stream,
+                     const vrt_options *opt)
+{
+    int rc = check_trace_args(h, dir_type, nrays, d_sp, d_sd, d_ep, d_ed, d_ei, d_rl, invscale, iterations);
+    if (rc) return rc;
+    DeviceGuard g(h->device);
+    return trace_device_impl(h, dir_type, nrays, d_sp, d_sd, d_ep, d_ed, d_ei, d_rl, d_path, invscale, iterations,
+                             (hipStream_t)stream, opt);
+}
+
+int vrt_trace(vrt_handle h, int dir_type, size_t nrays, const uint32_t *sp, const void *sd, uint32_t *ep, void *ed,
+              uint32_t *ei, uint32_t *rl, uint32_t *path, const float *invscale, uint32_t /*min_brightness*/,
+              uint32_t iterations, const vrt_options *opt)
+{
+    int rc = check_trace_args(h, dir_type, nrays, sp, sd, ep, ed, ei, rl, invscale, iterations);
+    if (rc) return rc;
+    if (nrays == 0) return VRT_OK;
+    vrt_engine *e = h;
+    DeviceGuard g(e->device);
+    const vrt_options &o = opt ? *opt : e->opt;
+    const size_t dsz = dir_type == VRT_F32 ? 4 : 2;
+    hipStream_t s = e->stream;
+
+    // Rays go up in one piece when no path is requested; with path tracing the device path
+    // buffer (iterations*12 bytes per ray) bounds the chunk, as the reference's 0x8000-ray
+    // chunks bound its own (.cu:798, 840).
+    size_t chunk = nrays;
+    if (path) {
+        const size_t per_ray = (size_t)iterations * 12;
+        const size_t budget = (size_t)2 << 30;
+        chunk = std::max<size_t>(1, std::min(nrays, budget / std::max<size_t>(per_ray, 1)));
+    }
+    HIP_TRY(e->h_in_pos.reserve(chunk * 12));
+    HIP_TRY(e->h_in_dir.reserve(chunk * 3 * dsz));
+    HIP_TRY(e->h_out_pos.reserve(chunk * 12));
+    HIP_TRY(e->h_out_dir.reserve(chunk * 3 * dsz));
+    HIP_TRY(e->h_out_iter.reserve(chunk * 4));
+    HIP_TRY(e->h_out_light.reserve(chunk * 4));
+    if (path) HIP_TRY(e->h_path.reserve(chunk * (size_t)iterations * 12));
+
+    const size_t nchunks = (nrays + chunk - 1) / chunk;
+    bool cap_hit = false;
+    for (size_t c = 0, off = 0; off < nrays; ++c, off += chunk) {
+        const size_t n = std::min(chunk, nrays - off);
+        if (o.loglevel < 0) printf("iteration %zu of %zu\n", c, nchunks);          // .cu:823-826
+        HIP_TRY(hipMemcpyAsync(e->h_in_pos.p, sp + 3 * off, n * 12, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(e->h_in_dir.p, (const char *)sd + 3 * off * dsz, n * 3 * dsz, hipMemcpyHostToDevice, s));
+        rc = trace_device_impl(e, dir_type, n, (const uint32_t *)e->h_in_pos.p, e->h_in_dir.p,
+                               (uint32_t *)e->h_out_pos.p, e->h_out_dir.p, (uint32_t *)e->h_out_iter.p,
+                               (uint32_t *)e->h_out_light.p, path ? (uint32_t *)e->h_path.p : nullptr, invscale,
+                               iterations, s, opt);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(ep + 3 * off, e->h_out_pos.p, n * 12, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync((char *)ed + 3 * off * dsz, e->h_out_dir.p, n * 3 * dsz, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(ei + off, e->h_out_iter.p, n * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(rl + off, e->h_out_light.p, n * 4, hipMemcpyDeviceToHost, s));
+        if (path)
+            HIP_TRY(hipMemcpyAsync(path + off * (size_t)iterations * 3, e->h_path.p, n * (size_t)iterations * 12,
+                                   hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    for (size_t i = 0; i < nrays && !cap_hit; ++i) cap_hit = (ei[i] == iterations);
+    if (cap_hit) printf("Warning, maximum iterations hitted\n");                   // .cu:512-515
+    if (o.loglevel < 0) printf("cpu: 0 gpu: %zu\n", nchunks);                      // .cu:948-951
+    return VRT_OK;
+}
+
+void vrt_destroy(vrt_handle h) { engine_free(h); }
+
+int vrt_engine_device(vrt_handle h) { return h ? h->device : -1; }
+size_t vrt_engine_field_bytes(vrt_handle h) { return h ? h->field_bytes : 0; }
+const void *vrt_engine_field_device_ptr(vrt_handle h) { return h ? h->field : nullptr; }
+
+}  // extern "C"

@@ -1,0 +1,219 @@
+// vrt_march.h -- device-side ray march for gfx950 (CDNA4), exact-arithmetic core.
+//
+// Restates, for the GPU, the live semantics of the reference's per-ray loop
+//   trace_ray_function   /root/reference/src/cuda_volume_raytracer.cu:317-374
+//   interpolatef (3-D)   /root/reference/src/cuda_volume_raytracer.cu:130-155
+//   __float2int_rn2      /root/reference/src/tuple_math.h:270-278  (host: std::round)
+// with the floating-point operation order of the reference's *CPU* build (g++ -O2 -mfma
+// contracts a*b + c*d to fma(a, b, c*d)); every fma below is explicit and this file is
+// compiled with -ffp-contract=off, so results are bit-identical to that build.
+//
+// Not a translation of the CUDA kernel (.cu:397-414, one thread per ray over AoS raydata_t):
+// rays are consumed from the caller's SoA arrays through an optional tile-order
+// permutation, the field is read as 16-byte (fp32) / 8-byte (int16) voxels, and the LDS
+// slab kernel below lets a 64-lane wavefront stage the voxel brick it is about to walk.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vrt {
+
+struct MarchParams {
+    const void *field;        // AoS {dx,dy,dz,w} per voxel, index ((x*By)+y)*Bz+z
+    uint32_t Bx, By, Bz;      // field extents
+    float invx, invy, invz;   // invscale
+    const uint32_t *start_pos;
+    const void *start_dir;
+    uint32_t *end_pos;
+    void *end_dir;
+    uint32_t *end_iter;
+    uint32_t *remaining_light;
+    uint32_t *path;           // nullptr unless PATH
+    const uint32_t *order;    // nullptr = identity; else ray processed by slot i is order[i]
+    uint32_t iterations;
+    uint32_t nrays;
+    uint32_t slab_lds_bytes;  // slab kernel: LDS bytes per wave
+};
+
+struct f4 { float x, y, z, w; };
+
+// ---- exact helpers -----------------------------------------------------------------------
+
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// a*wl + b*wr as the reference object computes it: fma(a, wl, b*wr)
+__device__ __forceinline__ float lerp_(float a, float wl, float b, float wr) { return fma_(a, wl, b * wr); }
+
+// std::round (half away from zero) followed by x86 cvttss2si (out of range / NaN -> INT_MIN)
+__device__ __forceinline__ int32_t round_to_i32(float x)
+{
+    float t = __builtin_truncf(x);
+    float d = x - t;                                   // exact
+    if (__builtin_fabsf(d) >= 0.5f) t += __builtin_copysignf(1.0f, x);
+    int32_t r = (int32_t)t;
+    if (!(__builtin_fabsf(t) < 2147483648.0f)) r = (int32_t)0x80000000;
+    return r;
+}
+
+// ---- voxel pair loads: voxel z and z+1 at one (x,y), as 2 x f4 --------------------------
+
+struct __attribute__((aligned(16))) vox_f32 { float c[4]; };
+struct __attribute__((aligned(8)))  vox_i16 { int16_t c[4]; };
+
+template <typename FieldT> struct FieldTraits;
+template <> struct FieldTraits<float>   { using vox = vox_f32; static constexpr int kVoxBytes = 16; };
+template <> struct FieldTraits<int16_t> { using vox = vox_i16; static constexpr int kVoxBytes = 8; };
+
+__device__ __forceinline__ void cvt_vox(const vox_f32 &v, f4 &o) { o.x = v.c[0]; o.y = v.c[1]; o.z = v.c[2]; o.w = v.c[3]; }
+__device__ __forceinline__ void cvt_vox(const vox_i16 &v, f4 &o)
+{
+    o.x = (float)v.c[0]; o.y = (float)v.c[1]; o.z = (float)v.c[2]; o.w = (float)v.c[3];
+}
+
+// ---- one march step given the 8 corners ------------------------------------------------
+// c[k]: k = 4*hi_x + 2*hi_y + hi_z.  Returns true if the ray terminates on the w>0 test.
+
+struct Ray {
+    uint32_t px, py, pz;
+    float dx, dy, dz;        // internal scale, unit 1.0 == 65536 (.cu:328-331)
+};
+
+__device__ __forceinline__ bool march_step(Ray &r, const f4 (&c)[8], float invx, float invy, float invz)
+{
+    const float wrx = (float)(r.px & 0xFFFFu), wlx = (float)(0x10000u - (r.px & 0xFFFFu));
+    const float wry = (float)(r.py & 0xFFFFu), wly = (float)(0x10000u - (r.py & 0xFFFFu));
+    const float wrz = (float)(r.pz & 0xFFFFu), wlz = (float)(0x10000u - (r.pz & 0xFFFFu));
+
+    // opacity channel (.cu:343): only the sign of the interpolated w matters.  If all eight
+    // corner values are <= 0 every product and fma below is <= 0; if all are > 0 the result is
+    // > 0 (the (0,0,0) corner has weight >= 1).  Only mixed neighbourhoods need the arithmetic.
+    const float wmax = fmaxf(fmaxf(fmaxf(c[0].w, c[1].w), fmaxf(c[2].w, c[3].w)),
+                             fmaxf(fmaxf(c[4].w, c[5].w), fmaxf(c[6].w, c[7].w)));
+    if (wmax > 0.0f) {
+        const float wmin = fminf(fminf(fminf(c[0].w, c[1].w), fminf(c[2].w, c[3].w)),
+                                 fminf(fminf(c[4].w, c[5].w), fminf(c[6].w, c[7].w)));
+        if (wmin > 0.0f) return true;
+        float a00 = lerp_(c[0].w, wlx, c[4].w, wrx), a01 = lerp_(c[1].w, wlx, c[5].w, wrx);
+        float a10 = lerp_(c[2].w, wlx, c[6].w, wrx), a11 = lerp_(c[3].w, wlx, c[7].w, wrx);
+        float b0 = lerp_(a00, wly, a10, wry), b1 = lerp_(a01, wly, a11, wry);
+        float w = lerp_(b0, wlz, b1, wrz) * (1.0f / 0x1000000000000p0f);
+        if (w > 0.0f) return true;
+    }
+    // NaN in the w channel: fmaxf drops NaNs, so a NaN corner can hide here only if the
+    // reference's result would be NaN (not > 0) as well -- same decision.
+
+    float g[3];
+    {
+        float a00, a01, a10, a11, b0, b1;
+#define VRT_CH(ch, out)                                                                         \
+        a00 = lerp_(c[0].ch, wlx, c[4].ch, wrx); a01 = lerp_(c[1].ch, wlx, c[5].ch, wrx);        \
+        a10 = lerp_(c[2].ch, wlx, c[6].ch, wrx); a11 = lerp_(c[3].ch, wlx, c[7].ch, wrx);        \
+        b0 = lerp_(a00, wly, a10, wry); b1 = lerp_(a01, wly, a11, wry);                          \
+        out = lerp_(b0, wlz, b1, wrz) * (1.0f / 0x1000000000000p0f);
+        VRT_CH(x, g[0]) VRT_CH(y, g[1]) VRT_CH(z, g[2])
+#undef VRT_CH
+    }
+    r.dx = fma_(g[0], invx, r.dx);                          // .cu:344-345
+    r.dy = fma_(g[1], invy, r.dy);
+    r.dz = fma_(g[2], invz, r.dz);
+    const float dot = fma_(r.dz, r.dz, fma_(r.dx, r.dx, r.dy * r.dy));
+    const float ilen = 0x42000000p0f / dot;                 // IEEE divide (.cu:346)
+    r.px += (uint32_t)round_to_i32((r.dx * invx) * ilen);   // .cu:347
+    r.py += (uint32_t)round_to_i32((r.dy * invy) * ilen);
+    r.pz += (uint32_t)round_to_i32((r.dz * invz) * ilen);
+    return false;
+}
+
+__device__ __forceinline__ bool in_field(const Ray &r, uint32_t bx1, uint32_t by1, uint32_t bz1)
+{
+    // uint16(pos>>16) < uint16(bounds-1), all components (.cu:335)
+    return (r.px >> 16) < bx1 && (r.py >> 16) < by1 && (r.pz >> 16) < bz1;
+}
+
+// ---- ray load / store (fill_struct / read_struct, .cu:468-516, 952-956) -----------------
+
+template <typename DirT>
+__device__ __forceinline__ void load_ray(const MarchParams &p, uint32_t ray, Ray &r)
+{
+    const uint32_t *sp = p.start_pos + 3 * (size_t)ray;
+    r.px = sp[0]; r.py = sp[1]; r.pz = sp[2];
+    const DirT *sd = (const DirT *)p.start_dir + 3 * (size_t)ray;
+    if constexpr (sizeof(DirT) == 4) {
+        r.dx = sd[0] * 65536.0f; r.dy = sd[1] * 65536.0f; r.dz = sd[2] * 65536.0f;
+    } else {
+        r.dx = (float)sd[0] * 256.0f; r.dy = (float)sd[1] * 256.0f; r.dz = (float)sd[2] * 256.0f;
+    }
+}
+
+template <typename DirT>
+__device__ __forceinline__ void store_ray(const MarchParams &p, uint32_t ray, const Ray &r, uint32_t remaining)
+{
+    uint32_t *ep = p.end_pos + 3 * (size_t)ray;
+    ep[0] = r.px; ep[1] = r.py; ep[2] = r.pz;
+    DirT *ed = (DirT *)p.end_dir + 3 * (size_t)ray;
+    if constexpr (sizeof(DirT) == 4) {
+        ed[0] = r.dx * (1.0f / 65536.0f); ed[1] = r.dy * (1.0f / 65536.0f); ed[2] = r.dz * (1.0f / 65536.0f);
+    } else {
+        ed[0] = (int16_t)round_to_i32(r.dx * (1.0f / 256.0f));
+        ed[1] = (int16_t)round_to_i32(r.dy * (1.0f / 256.0f));
+        ed[2] = (int16_t)round_to_i32(r.dz * (1.0f / 256.0f));
+    }
+    p.end_iter[ray] = p.iterations - remaining;
+    p.remaining_light[ray] = 0xFFFFFFFFu;
+}
+
+__device__ __forceinline__ void path_put(uint32_t *pb, uint32_t it, const Ray &r)
+{
+    uint32_t *q = pb + 3 * (size_t)it;
+    q[0] = r.px; q[1] = r.py; q[2] = r.pz;
+}
+
+// =========================================================================================
+// Kernel 1: DIRECT -- one lane per ray, corners gathered straight from the vector L1/L2.
+// =========================================================================================
+
+template <typename FieldT>
+__device__ __forceinline__ void gather_global(const typename FieldTraits<FieldT>::vox *f, const Ray &r,
+                                              uint32_t By, uint32_t Bz, f4 (&c)[8])
+{
+    using vox = typename FieldTraits<FieldT>::vox;
+    const size_t idx = ((size_t)((r.px >> 16) * By + (r.py >> 16))) * Bz + (r.pz >> 16);
+    const vox *b = f + idx;
+    const size_t sy = Bz, sx = (size_t)By * Bz;
+    vox v[8];
+    v[0] = b[0];       v[1] = b[1];
+    v[2] = b[sy];      v[3] = b[sy + 1];
+    v[4] = b[sx];      v[5] = b[sx + 1];
+    v[6] = b[sx + sy]; v[7] = b[sx + sy + 1];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cvt_vox(v[k], c[k]);
+}
+
+template <typename FieldT, typename DirT, bool PATH>
+__global__ __launch_bounds__(256) void k_march_direct(const MarchParams p)
+{
+    using vox = typename FieldTraits<FieldT>::vox;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= p.nrays) return;
+    const uint32_t ray = p.order ? p.order[slot] : slot;
+    Ray r;
+    load_ray<DirT>(p, ray, r);
+    const vox *f = (const vox *)p.field;
+    const uint32_t bx1 = (p.Bx - 1) & 0xFFFFu, by1 = (p.By - 1) & 0xFFFFu, bz1 = (p.Bz - 1) & 0xFFFFu;
+    uint32_t *pb = PATH ? p.path + (size_t)p.iterations * 3 * ray : nullptr;
+
+    uint32_t it = p.iterations - 1;                     // .cu:333
+    if (PATH) path_put(pb, it, r);
+    while (it-- > 0 && in_field(r, bx1, by1, bz1)) {    // .cu:335
+        f4 c[8];
+        gather_global<FieldT>(f, r, p.By, p.Bz, c);
+        if (march_step(r, c, p.invx, p.invy, p.invz)) break;
+        if (PATH) path_put(pb, it, r);
+    }
+    ++it;                                               // .cu:350
+    const uint32_t remaining = it;
+    if (PATH) { while (it-- > 0) path_put(pb, it, r); } // .cu:352-358
+    store_ray<DirT>(p, ray, r, remaining);
+}
+
+}  // namespace vrt
