@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the trace_rays hot path (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of rays: (tile-order) sort + march kernel on
+every rank and, for N > 1, the RCCL gather of the per-ray outputs to rank 0.  Inputs (field and
+rays) are resident in HBM before the timed region.  One process per GPU; the field is replicated,
+rays are sharded as contiguous row bands of the ray lattice (weak scaling: every rank marches the
+same number of rays).
+
+Prints ONE JSON line on rank 0 (see DESIGN.md §Measurement for the definitions):
+  value            = sum(end_iteration over all rays of all ranks) * K / wall time   [ray-steps/s]
+  roofline.achieved= 128 B (fp32 field; 64 B int16) * ray-steps of one launch / HIP-event
+                     duration of the march kernel, averaged over the K timed launches of rank 0
+  cpu_baseline     = the oracle (oracle/vrt_oracle.c, "port") or the real reference build
+                     (oracle/_ref, "reference") on a bounded sample of the same rays, same field
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from volumeraytracer_amd import capi, workloads as W  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+
+CONFIGS = {
+    # BASELINE.json configs[1..4]; config 1 is the CPU-only plumbing case (tests/test_oracle_golden.py)
+    2: dict(N=256, R=512, gen="perspective", field="f32", name="256^3 fp32 field, 512x512 perspective rays"),
+    3: dict(N=512, R=1024, gen="perspective", field="f32", name="512^3 fp32 field, 1024x1024 perspective rays"),
+    4: dict(N=512, R=2048, gen="perspective", field="f32", name="512^3 fp32 field, 2048x2048 perspective rays"),
+    5: dict(N=1024, R=1024, gen="ortho", field="i16", opaque=True,
+            name="1024^3 uint8+LUT volume expanded to the int16 field, 1024x1024 ortho rays, opaque cores"),
+    # small smoke-size config for quick checks
+    0: dict(N=96, R=256, gen="perspective", field="f32", name="96^3 fp32 field, 256x256 perspective rays (smoke)"),
+}
+
+
+def synth_field_device(N, field, dev, opaque=False, seed=1234, nblobs=4, amp=0.5):
+    """workloads.seam_field evaluated on the GPU with torch (float64), slab by slab.
+    Returns (bounds, [dx, dy, dz] device tensors, transl_cropped device tensor (int32 bits))."""
+    B = N - 2
+    c = torch.tensor(W.blob_centres(N, seed, nblobs), dtype=torch.float64, device=dev)
+    a = 16.0 / (N * N)
+    tdt = torch.float32 if field == "f32" else torch.int16
+    d = [torch.empty(B * B * B, dtype=tdt, device=dev) for _ in range(3)]
+    tr = torch.full((B * B * B,), -1, dtype=torch.int32, device=dev)     # 0xFFFFFFFF
+    y = torch.arange(1, N - 1, dtype=torch.float64, device=dev)[None, :, None]
+    z = torch.arange(1, N - 1, dtype=torch.float64, device=dev)[None, None, :]
+    CH = 16
+    for x0 in range(0, B, CH):
+        x1 = min(B, x0 + CH)
+        x = torch.arange(x0 + 1, x1 + 1, dtype=torch.float64, device=dev)[:, None, None]
+        n = torch.ones((x1 - x0, B, B), dtype=torch.float64, device=dev)
+        g = [torch.zeros_like(n) for _ in range(3)]
+        near = torch.zeros_like(n, dtype=torch.bool)
+        for k in range(nblobs):
+            dd = [x - c[k, 0], y - c[k, 1], z - c[k, 2]]
+            r2 = dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2]
+            e = amp * torch.exp(-r2 * a)
+            n = n + e
+            for j in range(3):
+                g[j] = g[j] - 2 * a * dd[j] * e
+            if opaque:
+                near |= r2 < (N / 10.0) ** 2
+        sl = slice(x0 * B * B, x1 * B * B)
+        for j in range(3):
+            v = g[j] / n * W.DIFF_PER_DLOGN
+            d[j][sl] = (v.to(torch.float32) if field == "f32" else torch.round(v).to(torch.int16)).reshape(-1)
+        if opaque:
+            tr[sl] = torch.where(near, torch.zeros((), dtype=torch.int32, device=dev),
+                                 torch.full((), -1, dtype=torch.int32, device=dev)).reshape(-1)
+    return [B, B, B], d, tr
+
+
+def make_rays(cfg, rank, world):
+    gen = W.perspective_rays if cfg["gen"] == "perspective" else W.ortho_rays
+    R = cfg["R"]
+    # weak scaling: a (R*world) x R lattice, rank r marches rows [r*R, (r+1)*R)
+    return gen(cfg["N"], R, rows_total=R * world, row_range=(rank * R, (rank + 1) * R))
+
+
+def cpu_baseline(field_host, bounds, sp, sd, inv, iterations, gpu_out, budget_s, log):
+    """Time the CPU checker on a bounded sample of this rank's rays (and verify the GPU on it)."""
+    import oracle
+    n = sp.size // 3
+    sp3, sd3 = sp.reshape(-1, 3), sd.reshape(-1, 3)
+    threads = oracle.port.num_threads()
+    # calibrate on 1024 evenly spread rays
+    idx = np.linspace(0, n - 1, min(n, 1024)).astype(np.int64)
+    t0 = time.time()
+    out = oracle.port.trace(field_host, bounds, sp3[idx].reshape(-1), sd3[idx].reshape(-1), inv, iterations)
+    dt = max(time.time() - t0, 1e-4)
+    steps = int(out["end_iteration"].astype(np.int64).sum())
+    rate = steps / dt
+    mean_steps = steps / idx.size
+    m = int(min(n, max(idx.size, budget_s * rate / max(mean_steps, 1.0))))
+    idx = np.linspace(0, n - 1, m).astype(np.int64)
+    t0 = time.time()
+    out = oracle.port.trace(field_host, bounds, sp3[idx].reshape(-1), sd3[idx].reshape(-1), inv, iterations)
+    dt = time.time() - t0
+    steps = int(out["end_iteration"].astype(np.int64).sum())
+    ok = (np.array_equal(out["end_position"].reshape(-1, 3), gpu_out["end_position"].reshape(-1, 3)[idx])
+          and np.array_equal(out["end_iteration"], gpu_out["end_iteration"][idx])
+          and np.array_equal(out["end_direction"].reshape(-1, 3).view(np.uint32),
+                             gpu_out["end_direction"].reshape(-1, 3)[idx].view(np.uint32)))
+    res = {"value": steps / dt, "unit": "ray-steps/s", "cores": threads, "kind": "port",
+           "sample": "%d of %d rays (evenly strided), %d ray-steps, %.2f s, OpenMP %d threads" % (m, n, steps, dt, threads),
+           "gpu_matches_bit_exact": bool(ok)}
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
+    ap.add_argument("--kernel", default="auto", choices=["auto", "direct", "slab"])
+    ap.add_argument("--sort", type=int, default=0, help="0 auto, 1 force tile order, -1 caller order")
+    ap.add_argument("--lds-bytes", type=int, default=0)
+    ap.add_argument("--iterations", type=int, default=100000)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget; 0 disables it")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs a torch.distributed.run launch with %d ranks" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+
+    def log(*a):
+        if rank == 0:
+            print("[bench]", *a, file=sys.stderr, flush=True)
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+
+    cfg = CONFIGS[args.config]
+    N = cfg["N"]
+    t0 = time.time()
+    bounds, d, tr = synth_field_device(N, cfg["field"], dev, opaque=cfg.get("opaque", False))
+    torch.cuda.synchronize()
+    ftype = capi.VRT_F32 if cfg["field"] == "f32" else capi.VRT_I16
+    eng = capi.Engine.from_device(bounds, [x.data_ptr() for x in d], tr.data_ptr(), ftype, d[0].numel())
+    log("field %s built on device in %.1f s (%.2f GB resident)" % (cfg["name"], time.time() - t0, eng.field_bytes / 1e9))
+
+    sp, sd = make_rays(cfg, rank, world)
+    n = sp.size // 3
+    d_sp = torch.from_numpy(sp.view(np.int32)).to(dev)
+    d_sd = torch.from_numpy(sd).to(dev)
+    # one contiguous output record per rank: [end_pos 3n | end_dir 3n | end_iter n | light n] (32 B/ray)
+    out = torch.empty(8 * n, dtype=torch.int32, device=dev)
+    o_ep, o_ed, o_ei, o_rl = out[0:3 * n], out[3 * n:6 * n], out[6 * n:7 * n], out[7 * n:8 * n]
+    gathered = [torch.empty_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
+    inv = [1.0, 1.0, 1.0]
+    kern = {"auto": capi.KERNEL_AUTO, "direct": capi.KERNEL_DIRECT, "slab": capi.KERNEL_SLAB}[args.kernel]
+    opts = capi.default_options(kernel=kern, sort_rays=args.sort, slab_lds_bytes=args.lds_bytes)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        eng.trace_device(capi.VRT_F32, n, d_sp.data_ptr(), d_sd.data_ptr(), o_ep.data_ptr(), o_ed.data_ptr(),
+                         o_ei.data_ptr(), o_rl.data_ptr(), inv, args.iterations, stream=stream, options=opts)
+        if world > 1:
+            dist.gather(out, gathered, dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_begin = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_begin
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-launch kernel duration from HIP events on the launch stream: re-run the K launches one by
+    # one (same inputs, same kernel) outside the wall-clock region so reading the events adds no sync to it
+    kernel_ms = []
+    for _ in range(args.steps):
+        eng.trace_device(capi.VRT_F32, n, d_sp.data_ptr(), d_sd.data_ptr(), o_ep.data_ptr(), o_ed.data_ptr(),
+                         o_ei.data_ptr(), o_rl.data_ptr(), inv, args.iterations, stream=stream, options=opts)
+        kernel_ms.append(eng.last_march_ms())
+    torch.cuda.synchronize()
+
+    steps_local = int(o_ei.to(torch.int64).sum().item())
+    steps_total = steps_local
+    if world > 1:
+        t = torch.tensor([steps_local], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        steps_total = int(t.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    bytes_per_step = 128 if cfg["field"] == "f32" else 64
+    kavg_ms = float(np.mean(kernel_ms))
+    achieved = steps_local * bytes_per_step / (kavg_ms * 1e-3) / 1e9
+    traffic = None
+    if os.path.exists(args.traffic_json):
+        try:
+            tj = json.load(open(args.traffic_json))
+            traffic = tj.get("config%d" % args.config, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    result = {
+        "metric": "ray-steps/sec",
+        "value": steps_total * args.steps / elapsed,
+        "unit": "ray-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": cfg["name"] + ", invscale 1, cap %d" % args.iterations,
+                   "rays_per_gpu": n, "ray_steps_per_gpu": steps_local, "field_bytes": eng.field_bytes,
+                   "kernel": args.kernel, "sort": args.sort, "parallelism": "rays sharded in %d row bands, field replicated, RCCL gather to rank 0" % world if world > 1 else "single GPU"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel_ms": kavg_ms, "algorithmic_bytes_per_ray_step": bytes_per_step},
+    }
+    if args.cpu_seconds > 0:
+        host = [x.cpu().numpy() for x in d]
+        tc_host = tr.cpu().numpy().view(np.uint32)
+        import oracle
+        field_host = oracle.port.interleave(host[0], host[1], host[2], tc_host)
+        del host
+        gpu_out = dict(end_position=o_ep.cpu().numpy().view(np.uint32),
+                       end_direction=o_ed.cpu().numpy().view(np.float32),
+                       end_iteration=o_ei.cpu().numpy().view(np.uint32))
+        result["cpu_baseline"] = cpu_baseline(field_host, bounds, sp, sd, inv, args.iterations, gpu_out,
+                                              args.cpu_seconds, log)
+    print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

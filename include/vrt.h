@@ -58,7 +58,8 @@ typedef struct vrt_options {
     int32_t  device;         /* extension: HIP device ordinal, -1 = current device */
     int32_t  kernel;         /* extension: VRT_KERNEL_* selector, 0 = auto */
     int32_t  sort_rays;      /* extension: 0 = auto, 1 = force tile ordering, -1 = keep caller order */
-    int32_t  reserved[5];
+    int32_t  slab_lds_bytes; /* extension: LDS bytes per wavefront for the slab kernel, 0 = default */
+    int32_t  reserved[4];
 } vrt_options;
 
 #define VRT_KERNEL_AUTO   0
@@ -138,6 +139,10 @@ void vrt_destroy(vrt_handle h);
 int    vrt_engine_device(vrt_handle h);             /* device ordinal the field lives on */
 size_t vrt_engine_field_bytes(vrt_handle h);        /* resident interleaved field size */
 const void *vrt_engine_field_device_ptr(vrt_handle h);
+/* Duration in milliseconds of the most recent march kernel launched through this engine,
+ * from HIP events recorded on the launch stream around the kernel (waits for it to finish).
+ * Negative if nothing has been launched.  Used by bench.py for the roofline figure. */
+float vrt_engine_last_march_ms(vrt_handle h);
 
 /* Message of the last failure on this thread ("" if none).  Valid until the next failing call. */
 const char *vrt_last_error(void);

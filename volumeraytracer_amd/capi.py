@@ -18,7 +18,7 @@ KERNEL_AUTO, KERNEL_DIRECT, KERNEL_SLAB = 0, 1, 2
 ABI_SYMBOLS = (
     "vrt_options_default", "vrt_device_count", "vrt_abi_version", "vrt_create", "vrt_create_from_device",
     "vrt_trace", "vrt_trace_device", "vrt_destroy", "vrt_engine_device", "vrt_engine_field_bytes",
-    "vrt_engine_field_device_ptr", "vrt_last_error",
+    "vrt_engine_field_device_ptr", "vrt_engine_last_march_ms", "vrt_last_error",
 )
 
 
@@ -34,7 +34,7 @@ class Options(C.Structure):
     """struct vrt_options == the reference's struct Options (types.h:83-91) + extensions."""
     _fields_ = [("loglevel", C.c_int32), ("minimum_gpu", C.c_uint64), ("write_instance", C.c_int32),
                 ("max_cpu", C.c_uint64), ("device", C.c_int32), ("kernel", C.c_int32),
-                ("sort_rays", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("sort_rays", C.c_int32), ("slab_lds_bytes", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 _lib = None
@@ -50,6 +50,15 @@ def load():
     if _lib is not None:
         return _lib
     path = lib_path()
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64
+    # (same SONAME as /opt/rocm's).  If our library pulled in the system copy first, torch would
+    # later fail with "No HIP GPUs are available".  torch is only plumbing here (device memory,
+    # streams, torch.distributed), but it has to come first.
+    if os.environ.get("VRT_NO_TORCH_PRELOAD", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(path):
         raise ImportError("libvrt_hip.so not built: run `python -m volumeraytracer_amd._build` "
                           "(or __graft_entry__.build()); there is no CPU fallback")
@@ -73,6 +82,8 @@ def load():
     L.vrt_engine_field_bytes.restype = sz
     L.vrt_engine_field_device_ptr.argtypes = [vp]
     L.vrt_engine_field_device_ptr.restype = vp
+    L.vrt_engine_last_march_ms.argtypes = [vp]
+    L.vrt_engine_last_march_ms.restype = C.c_float
     if hasattr(L, "vrt_scene_create"):
         L.vrt_scene_create.argtypes = [C.POINTER(vp), C.c_int, vp, C.c_int, vp, u32p, sz, C.POINTER(Options)]
         L.vrt_scene_trace.argtypes = [vp, C.c_int, sz, u32p, vp, u32p, vp, u32p, u32p, u32p, vp, C.c_uint32,
@@ -161,6 +172,10 @@ class Engine:
     @property
     def field_bytes(self):
         return int(load().vrt_engine_field_bytes(self._h))
+
+    def last_march_ms(self):
+        """HIP-event duration of the most recent march kernel (waits for it)."""
+        return float(load().vrt_engine_last_march_ms(self._h))
 
     def trace(self, start_pos, start_dir, invscale, iterations, trace_paths=False, min_brightness=0, options=None):
         """vrt_trace on host numpy arrays; returns dict of numpy outputs."""

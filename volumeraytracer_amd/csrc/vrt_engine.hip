@@ -80,6 +80,8 @@ struct vrt_engine {
     void *field = nullptr;         // interleaved AoS field, resident for the engine's lifetime
     size_t field_bytes = 0;
     hipStream_t stream = nullptr;  // used by the host-pointer entry point
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;   // around the most recent march kernel
+    bool ev_valid = false;
     int num_cu = 256;
     // workspaces (grow-only; no allocation in steady state)
     DevBuf sort_keys, sort_keys_alt, sort_vals, sort_vals_alt, sort_tmp;
@@ -180,6 +182,8 @@ int engine_init_device(vrt_engine *e)
     HIP_TRY(hipGetDeviceProperties(&prop, e->device));
     e->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&e->ev_begin));
+    HIP_TRY(hipEventCreate(&e->ev_end));
     // +64 bytes of zeroed tail so that a 16-byte pair load at the very last voxel stays inside
     // the allocation (the march never reads it: the loop requires pos>>16 < bounds-1).
     HIP_TRY(hipMalloc(&e->field, e->field_bytes + 64));
@@ -193,6 +197,8 @@ void engine_free(vrt_engine *e)
     DeviceGuard g(e->device);
     if (e->stream) { (void)hipStreamSynchronize(e->stream); (void)hipStreamDestroy(e->stream); }
     if (e->field) (void)hipFree(e->field);
+    if (e->ev_begin) (void)hipEventDestroy(e->ev_begin);
+    if (e->ev_end) (void)hipEventDestroy(e->ev_end);
     DevBuf *bufs[] = {&e->sort_keys, &e->sort_keys_alt, &e->sort_vals, &e->sort_vals_alt, &e->sort_tmp,
                       &e->h_in_pos, &e->h_in_dir, &e->h_out_pos, &e->h_out_dir, &e->h_out_iter, &e->h_out_light,
                       &e->h_path};
@@ -234,6 +240,11 @@ int trace_device_impl(vrt_engine *e, int dir_type, size_t nrays, const uint32_t 
     p.iterations = iterations;
     p.nrays = (uint32_t)nrays;
     p.slab_lds_bytes = 0;
+    if (o.slab_lds_bytes > 0) {
+        if (o.slab_lds_bytes < 1024 || o.slab_lds_bytes > 40960 || (o.slab_lds_bytes & 15))
+            return fail(VRT_ERR_INVALID_ARGUMENT, "slab_lds_bytes must be a multiple of 16 in [1024, 40960]");
+        p.slab_lds_bytes = (uint32_t)o.slab_lds_bytes;
+    }
 
     int kernel = o.kernel;
     if (kernel == VRT_KERNEL_AUTO) kernel = d_path ? VRT_KERNEL_DIRECT : VRT_KERNEL_SLAB;
@@ -252,12 +263,16 @@ int trace_device_impl(vrt_engine *e, int dir_type, size_t nrays, const uint32_t 
         p.order = order;
     }
 
-    if (e->field_type == VRT_F32) {
-        if (dir_type == VRT_F32) return launch_typed<float, float>(e, p, kernel, s);
-        return launch_typed<float, int16_t>(e, p, kernel, s);
-    }
-    if (dir_type == VRT_F32) return launch_typed<int16_t, float>(e, p, kernel, s);
-    return launch_typed<int16_t, int16_t>(e, p, kernel, s);
+    HIP_TRY(hipEventRecord(e->ev_begin, s));
+    int rc;
+    if (e->field_type == VRT_F32)
+        rc = dir_type == VRT_F32 ? launch_typed<float, float>(e, p, kernel, s) : launch_typed<float, int16_t>(e, p, kernel, s);
+    else
+        rc = dir_type == VRT_F32 ? launch_typed<int16_t, float>(e, p, kernel, s) : launch_typed<int16_t, int16_t>(e, p, kernel, s);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(e->ev_end, s));
+    e->ev_valid = true;
+    return VRT_OK;
 }
 
 int check_trace_args(vrt_handle h, int dir_type, size_t nrays, const void *sp, const void *sd, const void *ep,
@@ -438,5 +453,15 @@ void vrt_destroy(vrt_handle h) { engine_free(h); }
 int vrt_engine_device(vrt_handle h) { return h ? h->device : -1; }
 size_t vrt_engine_field_bytes(vrt_handle h) { return h ? h->field_bytes : 0; }
 const void *vrt_engine_field_device_ptr(vrt_handle h) { return h ? h->field : nullptr; }
+
+float vrt_engine_last_march_ms(vrt_handle h)
+{
+    if (!h || !h->ev_valid) return -1.0f;
+    DeviceGuard g(h->device);
+    float ms = -1.0f;
+    if (hipEventSynchronize(h->ev_end) != hipSuccess) return -1.0f;
+    if (hipEventElapsedTime(&ms, h->ev_begin, h->ev_end) != hipSuccess) return -1.0f;
+    return ms;
+}
 
 }  // extern "C"

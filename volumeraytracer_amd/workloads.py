@@ -99,25 +99,34 @@ def _finish_seam_rays(pv, dirs, N, dir_dtype, seed, nblobs, amp):
     return pos.astype(np.uint32).reshape(-1), sd.reshape(-1)
 
 
-def ortho_rays(N, R, dir_dtype=np.float32, seed=1234, nblobs=4, amp=0.5):
+def _lattice(lo, hi, R, rows_total, row_range):
+    """(row, col) coordinates of a rows_total x R lattice over [lo, hi]^2, restricted to the
+    contiguous band of rows row_range = (r0, r1) (one band per GPU)."""
+    rows_total = R if rows_total is None else rows_total
+    r0, r1 = (0, rows_total) if row_range is None else row_range
+    tr = np.linspace(lo, hi, rows_total)[r0:r1]
+    tc = np.linspace(lo, hi, R)
+    return np.meshgrid(tr, tc, indexing="ij")
+
+
+def ortho_rays(N, R, dir_dtype=np.float32, seed=1234, nblobs=4, amp=0.5, rows_total=None, row_range=None):
     """R x R axis-parallel rays: start x = 1.5, (y,z) on a regular lattice over [1.5, N-2.5]
     (volume voxels), direction +x.  Ray index = iy * R + iz (z minor)."""
-    t = np.linspace(1.5, N - 2.5, R)
-    yy, zz = np.meshgrid(t, t, indexing="ij")
-    pv = np.stack([np.full(R * R, 1.5), yy.reshape(-1), zz.reshape(-1)], 1)
+    yy, zz = _lattice(1.5, N - 2.5, R, rows_total, row_range)
+    pv = np.stack([np.full(yy.size, 1.5), yy.reshape(-1), zz.reshape(-1)], 1)
     dirs = np.zeros_like(pv)
     dirs[:, 0] = 1.0
     return _finish_seam_rays(pv, dirs, N, dir_dtype, seed, nblobs, amp)
 
 
-def perspective_rays(N, R, fov_deg=40.0, dir_dtype=np.float32, seed=1234, nblobs=4, amp=0.5):
+def perspective_rays(N, R, fov_deg=40.0, dir_dtype=np.float32, seed=1234, nblobs=4, amp=0.5, rows_total=None,
+                     row_range=None):
     """R x R pinhole rays: eye at (-N, N/2, N/2), lattice over a fov_deg cone, clipped to the
     entry plane x = 1.5 (volume voxels)."""
     eye = np.array([-float(N), N / 2.0, N / 2.0])
     h = np.tan(np.radians(fov_deg) / 2.0)
-    t = np.linspace(-h, h, R)
-    uu, vv = np.meshgrid(t, t, indexing="ij")
-    dirs = np.stack([np.ones(R * R), uu.reshape(-1), vv.reshape(-1)], 1)
+    uu, vv = _lattice(-h, h, R, rows_total, row_range)
+    dirs = np.stack([np.ones(uu.size), uu.reshape(-1), vv.reshape(-1)], 1)
     dirs /= np.linalg.norm(dirs, axis=1)[:, None]
     s = (1.5 - eye[0]) / dirs[:, 0]
     pv = eye[None, :] + dirs * s[:, None]
