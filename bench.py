@@ -209,6 +209,11 @@ def main():
         kernel_ms.append(eng.last_march_ms())
     torch.cuda.synchronize()
 
+    if os.environ.get("VRT_DEBUG_STATS") == "1" and rank == 0:
+        try:
+            log("slab debug stats:", eng.debug_stats())
+        except Exception as ex:
+            log("no debug stats:", ex)
     steps_local = int(o_ei.to(torch.int64).sum().item())
     steps_total = steps_local
     if world > 1:

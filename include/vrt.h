@@ -143,6 +143,9 @@ const void *vrt_engine_field_device_ptr(vrt_handle h);
  * from HIP events recorded on the launch stream around the kernel (waits for it to finish).
  * Negative if nothing has been launched.  Used by bench.py for the roofline figure. */
 float vrt_engine_last_march_ms(vrt_handle h);
+/* Development aid: with VRT_DEBUG_STATS=1 in the environment the slab kernel counts planning
+ * rounds / staged voxels / LDS steps; this copies up to n (<= 64) counters of the last launch. */
+int vrt_engine_debug_stats(vrt_handle h, unsigned long long *out, int n);
 
 /* Message of the last failure on this thread ("" if none).  Valid until the next failing call. */
 const char *vrt_last_error(void);

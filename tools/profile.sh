@@ -12,10 +12,12 @@ cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $REPO/bench.py --cpu-seconds 0 --steps 3 --warmup 1 $*"
 echo "== kernel trace" 
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH > "$OUT/trace.json" 2> "$OUT/trace.err" || echo "trace pass failed"
+python3 $REPO/tools/summarize_prof.py "$OUT/trace" "$OUT/trace_summary.json"; rm -rf "$OUT/trace"
 pass() { # name counters...
   local name=$1; shift
   echo "== pmc $name: $*"
   rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/pmc_$name" -o pmc -- $BENCH > "$OUT/pmc_$name.json" 2> "$OUT/pmc_$name.err" || echo "pmc $name failed"
+  python3 $REPO/tools/summarize_prof.py "$OUT/pmc_$name" "$OUT/pmc_${name}_summary.json"; rm -rf "$OUT/pmc_$name"
 }
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE

@@ -18,7 +18,8 @@ KERNEL_AUTO, KERNEL_DIRECT, KERNEL_SLAB = 0, 1, 2
 ABI_SYMBOLS = (
     "vrt_options_default", "vrt_device_count", "vrt_abi_version", "vrt_create", "vrt_create_from_device",
     "vrt_trace", "vrt_trace_device", "vrt_destroy", "vrt_engine_device", "vrt_engine_field_bytes",
-    "vrt_engine_field_device_ptr", "vrt_engine_last_march_ms", "vrt_last_error",
+    "vrt_engine_field_device_ptr", "vrt_engine_last_march_ms", "vrt_engine_debug_stats",
+    "vrt_last_error",
 )
 
 
@@ -82,6 +83,7 @@ def load():
     L.vrt_engine_field_bytes.restype = sz
     L.vrt_engine_field_device_ptr.argtypes = [vp]
     L.vrt_engine_field_device_ptr.restype = vp
+    L.vrt_engine_debug_stats.argtypes = [vp, C.POINTER(C.c_ulonglong), C.c_int]
     L.vrt_engine_last_march_ms.argtypes = [vp]
     L.vrt_engine_last_march_ms.restype = C.c_float
     if hasattr(L, "vrt_scene_create"):
@@ -172,6 +174,14 @@ class Engine:
     @property
     def field_bytes(self):
         return int(load().vrt_engine_field_bytes(self._h))
+
+    def debug_stats(self):
+        """Slab-kernel debug counters of the last launch (needs VRT_DEBUG_STATS=1)."""
+        buf = (C.c_ulonglong * 16)()
+        check(load().vrt_engine_debug_stats(self._h, buf, 16))
+        names = ("rounds", "planned_K_sum", "lds_wave_steps", "direct_rounds", "direct_wave_steps", "vox_staged",
+                 "early_exit")
+        return dict(zip(names, [int(x) for x in buf]))
 
     def last_march_ms(self):
         """HIP-event duration of the most recent march kernel (waits for it)."""

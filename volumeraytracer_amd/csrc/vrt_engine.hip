@@ -14,6 +14,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <new>
 #include <string>
 
@@ -84,7 +85,8 @@ struct vrt_engine {
     bool ev_valid = false;
     int num_cu = 256;
     // workspaces (grow-only; no allocation in steady state)
-    DevBuf sort_keys, sort_keys_alt, sort_vals, sort_vals_alt, sort_tmp;
+    DevBuf sort_keys, sort_keys_alt, sort_vals, sort_vals_alt, sort_tmp, sort_bounds;
+    DevBuf stats;                  // debug counters, allocated only when VRT_DEBUG_STATS=1
     DevBuf h_in_pos, h_in_dir, h_out_pos, h_out_dir, h_out_iter, h_out_light, h_path;
     vrt_options opt;
 };
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256) void k_interleave_f32(const float *dx, const f
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
         vrt::vox_f32 v;
-        v.c[0] = dx[i]; v.c[1] = dy[i]; v.c[2] = dz[i]; v.c[3] = (float)w_channel(tr[i]);
+        v.x = dx[i]; v.y = dy[i]; v.z = dz[i]; v.w = (float)w_channel(tr[i]);
         out[i] = v;
     }
 }
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256) void k_interleave_i16(const int16_t *dx, const
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
         vrt::vox_i16 v;
-        v.c[0] = dx[i]; v.c[1] = dy[i]; v.c[2] = dz[i]; v.c[3] = (int16_t)w_channel(tr[i]);
+        v.x = dx[i]; v.y = dy[i]; v.z = dz[i]; v.w = (int16_t)w_channel(tr[i]);
         out[i] = v;
     }
 }
@@ -199,7 +201,7 @@ void engine_free(vrt_engine *e)
     if (e->field) (void)hipFree(e->field);
     if (e->ev_begin) (void)hipEventDestroy(e->ev_begin);
     if (e->ev_end) (void)hipEventDestroy(e->ev_end);
-    DevBuf *bufs[] = {&e->sort_keys, &e->sort_keys_alt, &e->sort_vals, &e->sort_vals_alt, &e->sort_tmp,
+    DevBuf *bufs[] = {&e->stats, &e->sort_keys, &e->sort_keys_alt, &e->sort_vals, &e->sort_vals_alt, &e->sort_tmp, &e->sort_bounds,
                       &e->h_in_pos, &e->h_in_dir, &e->h_out_pos, &e->h_out_dir, &e->h_out_iter, &e->h_out_light,
                       &e->h_path};
     for (DevBuf *b : bufs) b->release();
@@ -246,6 +248,12 @@ int trace_device_impl(vrt_engine *e, int dir_type, size_t nrays, const uint32_t 
         p.slab_lds_bytes = (uint32_t)o.slab_lds_bytes;
     }
 
+    p.stats = nullptr;
+    if (const char *dbg = getenv("VRT_DEBUG_STATS"); dbg && dbg[0] == '1') {
+        HIP_TRY(e->stats.reserve(64 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(e->stats.p, 0, 64 * sizeof(unsigned long long), s));
+        p.stats = (unsigned long long *)e->stats.p;
+    }
     int kernel = o.kernel;
     if (kernel == VRT_KERNEL_AUTO) kernel = d_path ? VRT_KERNEL_DIRECT : VRT_KERNEL_SLAB;
     if (kernel != VRT_KERNEL_DIRECT && kernel != VRT_KERNEL_SLAB)
@@ -257,7 +265,7 @@ int trace_device_impl(vrt_engine *e, int dir_type, size_t nrays, const uint32_t 
     if (sort) {
         const uint32_t *order = nullptr;
         hipError_t se = vrt::build_tile_order(d_sp, d_sd, dir_type, (uint32_t)nrays, e->sort_keys, e->sort_keys_alt,
-                                              e->sort_vals, e->sort_vals_alt, e->sort_tmp, s, &order);
+                                              e->sort_vals, e->sort_vals_alt, e->sort_tmp, e->sort_bounds, s, &order);
         if (se != hipSuccess) return fail(se == hipErrorOutOfMemory ? VRT_ERR_OUT_OF_MEMORY : VRT_ERR_HIP,
                                           "ray tile ordering failed: %s", hipGetErrorString(se));
         p.order = order;
@@ -453,6 +461,16 @@ void vrt_destroy(vrt_handle h) { engine_free(h); }
 int vrt_engine_device(vrt_handle h) { return h ? h->device : -1; }
 size_t vrt_engine_field_bytes(vrt_handle h) { return h ? h->field_bytes : 0; }
 const void *vrt_engine_field_device_ptr(vrt_handle h) { return h ? h->field : nullptr; }
+
+int vrt_engine_debug_stats(vrt_handle h, unsigned long long *out, int n)
+{
+    if (!h || !out || n <= 0) return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_engine_debug_stats: bad argument");
+    if (!h->stats.p) return fail(VRT_ERR_INVALID_ARGUMENT, "debug stats not enabled (set VRT_DEBUG_STATS=1)");
+    DeviceGuard g(h->device);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, h->stats.p, sizeof(unsigned long long) * (size_t)std::min(n, 64), hipMemcpyDeviceToHost));
+    return VRT_OK;
+}
 
 float vrt_engine_last_march_ms(vrt_handle h)
 {

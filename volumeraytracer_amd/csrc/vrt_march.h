@@ -33,6 +33,7 @@ struct MarchParams {
     uint32_t iterations;
     uint32_t nrays;
     uint32_t slab_lds_bytes;  // slab kernel: LDS bytes per wave
+    unsigned long long *stats; // optional debug counters (nullptr in production), see vrt_slab.h
 };
 
 struct f4 { float x, y, z, w; };
@@ -57,17 +58,17 @@ __device__ __forceinline__ int32_t round_to_i32(float x)
 
 // ---- voxel pair loads: voxel z and z+1 at one (x,y), as 2 x f4 --------------------------
 
-struct __attribute__((aligned(16))) vox_f32 { float c[4]; };
-struct __attribute__((aligned(8)))  vox_i16 { int16_t c[4]; };
+typedef float   vox_f32 __attribute__((ext_vector_type(4)));   // 16 B: {dx, dy, dz, w}
+typedef int16_t vox_i16 __attribute__((ext_vector_type(4)));   //  8 B
 
 template <typename FieldT> struct FieldTraits;
 template <> struct FieldTraits<float>   { using vox = vox_f32; static constexpr int kVoxBytes = 16; };
 template <> struct FieldTraits<int16_t> { using vox = vox_i16; static constexpr int kVoxBytes = 8; };
 
-__device__ __forceinline__ void cvt_vox(const vox_f32 &v, f4 &o) { o.x = v.c[0]; o.y = v.c[1]; o.z = v.c[2]; o.w = v.c[3]; }
+__device__ __forceinline__ void cvt_vox(const vox_f32 &v, f4 &o) { o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w; }
 __device__ __forceinline__ void cvt_vox(const vox_i16 &v, f4 &o)
 {
-    o.x = (float)v.c[0]; o.y = (float)v.c[1]; o.z = (float)v.c[2]; o.w = (float)v.c[3];
+    o.x = (float)v.x; o.y = (float)v.y; o.z = (float)v.z; o.w = (float)v.w;
 }
 
 // ---- one march step given the 8 corners ------------------------------------------------

@@ -9,11 +9,11 @@
 //   plan   wave-reduce (DPP) the live lanes' positions and per-step displacement; pick the
 //          largest step count K whose swept bounding brick (+1 voxel for the upper trilinear
 //          corners), clipped to the field, fits the segment
-//   stage  all 64 lanes copy the brick HBM/L2 -> LDS with 16-byte accesses (z is the
-//          memory-minor axis, so brick rows are contiguous runs)
+//   stage  all 64 lanes copy the brick L2/HBM -> LDS; every lane issues all of its (at most VPL)
+//          16-byte loads before the first LDS write, so one memory latency covers the brick
 //   march  up to K steps with all corners read from LDS (ds_read_b128); a ballot ends the
-//          round as soon as any live lane would leave the brick (rays bend, the plan is only
-//          a prediction) and ends the wavefront when every lane has terminated
+//          round as soon as a live lane would leave the brick (rays bend, the plan is only a
+//          prediction) and ends the wavefront when every lane has terminated
 //
 // Wavefronts whose rays do not fit a brick even for one step (incoherent rays) fall back to
 // the global gather for a few steps and re-plan.  Waves never synchronise with each other:
@@ -37,35 +37,49 @@ constexpr int kSlabDirectSteps = 16;    // global-gather steps for a wave that f
 
 __device__ __forceinline__ uint32_t sgpr(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// debug counters (MarchParams::stats != nullptr): per-wave events, added by lane 0
+enum { kStatRounds = 0, kStatPlannedK, kStatLdsWaveSteps, kStatDirectRounds, kStatDirectWaveSteps, kStatVoxStaged,
+       kStatEarlyExit, kStatCount };
+__device__ __forceinline__ void stat_add(const MarchParams &p, int which, unsigned long long v)
+{
+    if (p.stats && (threadIdx.x & 63u) == 0) atomicAdd(p.stats + which, v);
+}
+
 struct Brick {
-    uint32_t lox, loy, loz;   // first voxel
-    uint32_t ex, ey, ez;      // extents in voxels (>= 2 each when usable)
+    uint32_t lo[3];   // first voxel
+    uint32_t e[3];    // extents in voxels
 };
 
-// Plan the brick for K steps from wave-uniform extremes.  Positions are 16.16 in uint32, the
-// displacement extremes are int32 per step.  Returns the voxel count (0 if degenerate).
-__device__ __forceinline__ uint32_t plan_brick(const uint32_t pmin[3], const uint32_t pmax[3], const int32_t smin[3],
-                                               const int32_t smax[3], int K, const uint32_t B[3], Brick &b)
+// Wave-uniform planning inputs in 1/256-voxel units (24-bit positions), rounded outwards.
+struct PlanIn {
+    int32_t pmin8[3], pmax8[3];   // floor(pmin/256), ceil(pmax/256)
+    int32_t sneg8[3], spos8[3];   // min(floor(smin/256), 0), max(ceil(smax/256), 0), clamped to +-2^20
+};
+
+// Brick swept by the wave during K steps (positions before each of the steps k = 0..K-1), plus
+// one voxel for the upper trilinear corners, clipped to the field.  Returns the voxel count,
+// saturated to cap+1 when it cannot fit.  All 32-bit scalar arithmetic.
+__device__ __forceinline__ uint32_t plan_brick(const PlanIn &in, int K, const uint32_t B[3], uint32_t cap, Brick &b)
 {
-    uint32_t lo[3], ext[3];
+    uint32_t vol = 1;
+    bool big = false;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        // positions before each of the K steps: k = 0 .. K-1
-        int64_t a = (int64_t)pmin[d] + (int64_t)(K - 1) * (smin[d] < 0 ? smin[d] : 0);
-        int64_t c = (int64_t)pmax[d] + (int64_t)(K - 1) * (smax[d] > 0 ? smax[d] : 0);
-        if (a < 0) a = 0;
-        int64_t l = a >> 16;
-        int64_t h = (c >> 16) + 1;                       // +1: upper trilinear corner
-        const int64_t top = (int64_t)B[d] - 1;
-        if (h > top) h = top;
-        if (l > h) l = h;
-        lo[d] = (uint32_t)l;
-        ext[d] = (uint32_t)(h - l + 1);
+        int32_t a = in.pmin8[d] + (K - 1) * in.sneg8[d];
+        int32_t c = in.pmax8[d] + (K - 1) * in.spos8[d];
+        a = a < 0 ? 0 : a;
+        int32_t l = a >> 8;
+        int32_t h = (c >> 8) + 1;                        // +1: upper trilinear corner
+        const int32_t top = (int32_t)B[d] - 1;
+        h = h > top ? top : h;
+        l = l > h ? h : l;
+        b.lo[d] = (uint32_t)l;
+        b.e[d] = (uint32_t)(h - l + 1);
+        big |= b.e[d] > cap;
+        vol = big ? cap + 1 : vol * b.e[d];
+        big |= vol > cap;
     }
-    b.lox = lo[0]; b.loy = lo[1]; b.loz = lo[2];
-    b.ex = ext[0]; b.ey = ext[1]; b.ez = ext[2];
-    const uint64_t vol = (uint64_t)ext[0] * ext[1] * ext[2];
-    return vol > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)vol;
+    return big ? cap + 1 : vol;
 }
 
 template <typename FieldT>
@@ -83,14 +97,15 @@ __device__ __forceinline__ void gather_lds(const typename FieldTraits<FieldT>::v
     for (int k = 0; k < 8; ++k) cvt_vox(v[k], c[k]);
 }
 
-template <typename FieldT, typename DirT>
+// VPL = voxels staged per lane at most; the wave's LDS segment holds 64*VPL voxels.
+template <typename FieldT, typename DirT, int VPL>
 __global__ __launch_bounds__(64 * kSlabWavesPerBlock) void k_march_slab(const MarchParams p)
 {
     using vox = typename FieldTraits<FieldT>::vox;
+    constexpr uint32_t kCap = 64u * VPL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t wave = threadIdx.x >> 6;
-    vox *seg = (vox *)(smem + (size_t)wave * p.slab_lds_bytes);
-    const uint32_t cap_vox = p.slab_lds_bytes / sizeof(vox);
+    vox *seg = (vox *)smem + (size_t)wave * kCap;
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
@@ -112,42 +127,59 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock) void k_march_slab(const Ma
 
     for (;;) {
         bool live = !done && it > 0 && in_field(r, bx1, by1, bz1);
-        if (!live) done = true;
+        done = !live;
         if (__ballot(live) == 0ull) break;              // wave early-out: every lane has terminated
 
         // ---- plan -------------------------------------------------------------------------
-        int32_t s[3] = {0, 0, 0};
-        if (live) {                                     // per-step displacement estimate from the current direction
+        int32_t s[3];
+        {                                               // per-step displacement estimate from the current direction
             const float dot = fma_(r.dz, r.dz, fma_(r.dx, r.dx, r.dy * r.dy));
-            const float ilen = 0x42000000p0f / dot;
-            s[0] = round_to_i32((r.dx * invx) * ilen);
-            s[1] = round_to_i32((r.dy * invy) * ilen);
-            s[2] = round_to_i32((r.dz * invz) * ilen);
+            const float ilen = 0x42000000p0f * __builtin_amdgcn_rcpf(dot);   // estimate only
+            const float lim = 268435456.0f;             // 2^28
+            s[0] = (int32_t)fminf(fmaxf((r.dx * invx) * ilen, -lim), lim);
+            s[1] = (int32_t)fminf(fmaxf((r.dy * invy) * ilen, -lim), lim);
+            s[2] = (int32_t)fminf(fmaxf((r.dz * invz) * ilen, -lim), lim);
         }
-        uint32_t pmin[3], pmax[3];
-        int32_t smin[3], smax[3];
-        pmin[0] = sgpr(__ockl_wfred_min_u32(live ? r.px : 0xFFFFFFFFu)); pmax[0] = sgpr(__ockl_wfred_max_u32(live ? r.px : 0u));
-        pmin[1] = sgpr(__ockl_wfred_min_u32(live ? r.py : 0xFFFFFFFFu)); pmax[1] = sgpr(__ockl_wfred_max_u32(live ? r.py : 0u));
-        pmin[2] = sgpr(__ockl_wfred_min_u32(live ? r.pz : 0xFFFFFFFFu)); pmax[2] = sgpr(__ockl_wfred_max_u32(live ? r.pz : 0u));
+        PlanIn in;
+        {
+            const uint32_t px[3] = {r.px, r.py, r.pz};
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            smin[d] = (int32_t)sgpr((uint32_t)__ockl_wfred_min_i32(live ? s[d] : 0x7FFFFFFF));
-            smax[d] = (int32_t)sgpr((uint32_t)__ockl_wfred_max_i32(live ? s[d] : (int32_t)0x80000000));
+            for (int d = 0; d < 3; ++d) {
+                const uint32_t lo = sgpr(__ockl_wfred_min_u32(live ? px[d] : 0xFFFFFFFFu));
+                const uint32_t hi = sgpr(__ockl_wfred_max_u32(live ? px[d] : 0u));
+                const int32_t smn = (int32_t)sgpr((uint32_t)__ockl_wfred_min_i32(live ? s[d] : 0x7FFFFFFF));
+                const int32_t smx = (int32_t)sgpr((uint32_t)__ockl_wfred_max_i32(live ? s[d] : (int32_t)0x80000000));
+                in.pmin8[d] = (int32_t)(lo >> 8);
+                in.pmax8[d] = (int32_t)((hi >> 8) + 1);
+                int32_t a = smn >> 8, c = (smx >> 8) + 1;          // floor / ceil (+1 keeps it conservative)
+                a = a > 0 ? 0 : (a < -(1 << 20) ? -(1 << 20) : a);
+                c = c < 0 ? 0 : (c > (1 << 20) ? (1 << 20) : c);
+                in.sneg8[d] = a;
+                in.spos8[d] = c;
+            }
         }
         Brick bk;
         int K = kSlabMaxK;
-        uint32_t vol = plan_brick(pmin, pmax, smin, smax, K, B, bk);
-        while (vol > cap_vox && K > 1) {
+        uint32_t vol = plan_brick(in, K, B, kCap, bk);
+        while (vol > kCap && K > 1) {
             K >>= 1;
-            vol = plan_brick(pmin, pmax, smin, smax, K, B, bk);
+            vol = plan_brick(in, K, B, kCap, bk);
+        }
+        if (vol <= kCap && K >= 2 && K < kSlabMaxK) {   // the halving search is coarse: try 1.5 K
+            Brick b2;
+            const int K2 = K + (K >> 1);
+            const uint32_t v2 = plan_brick(in, K2, B, kCap, b2);
+            if (v2 <= kCap) { K = K2; vol = v2; bk = b2; }
         }
 
-        if (vol > cap_vox || bk.ex < 2 || bk.ey < 2 || bk.ez < 2) {
+        if (vol > kCap || bk.e[0] < 2 || bk.e[1] < 2 || bk.e[2] < 2) {
             // ---- incoherent wave: gather from global memory for a few steps, then re-plan ----
+            stat_add(p, kStatDirectRounds, 1);
             for (int k = 0; k < kSlabDirectSteps; ++k) {
                 live = !done && it > 0 && in_field(r, bx1, by1, bz1);
-                if (!live) done = true;
+                done = !live;
                 if (__ballot(live) == 0ull) break;
+                stat_add(p, kStatDirectWaveSteps, 1);
                 if (live) {
                     f4 c[8];
                     gather_global<FieldT>(f, r, p.By, p.Bz, c);
@@ -157,42 +189,57 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock) void k_march_slab(const Ma
             continue;
         }
 
+        stat_add(p, kStatRounds, 1);
+        stat_add(p, kStatPlannedK, (unsigned long long)K);
+        stat_add(p, kStatVoxStaged, vol);
+        const uint32_t ey = bk.e[1], ez = bk.e[2];
         // ---- stage: brick -> LDS ----------------------------------------------------------
         {
-            const uint32_t ez = bk.ez, eyz = bk.ey * bk.ez;
             // exact division by the wave-uniform extents via 2^32 reciprocals (v < 2^16)
-            const uint32_t mz = ez > 1 ? (uint32_t)(0x100000000ull / ez) + 1u : 0u;
-            const uint32_t my = bk.ey > 1 ? (uint32_t)(0x100000000ull / bk.ey) + 1u : 0u;
+            const uint32_t mz = (uint32_t)(0x100000000ull / ez) + 1u;     // ez >= 2
+            const uint32_t my = (uint32_t)(0x100000000ull / ey) + 1u;     // ey >= 2
             const size_t gsy = p.Bz, gsx = (size_t)p.By * p.Bz;
-            const vox *g0 = f + ((size_t)bk.lox * p.By + bk.loy) * p.Bz + bk.loz;
+            const vox *g0 = f + ((size_t)bk.lo[0] * p.By + bk.lo[1]) * p.Bz + bk.lo[2];
+            vox tmp[VPL];
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                const uint32_t v = lane + 64u * j;
+                const uint32_t vc = v < vol ? v : 0u;                 // clamp: lanes past the end re-read voxel 0
+                const uint32_t t = __umulhi(vc, mz);                  // vc / ez
+                const uint32_t lz = vc - t * ez;
+                const uint32_t lx = __umulhi(t, my);                  // t / ey
+                const uint32_t ly = t - lx * ey;
+                tmp[j] = g0[(size_t)lx * gsx + (size_t)ly * gsy + lz];
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");    // previous round's LDS reads are done
-            for (uint32_t v = lane; v < vol; v += 64) {
-                const uint32_t t = ez > 1 ? __umulhi(v, mz) : v;           // v / ez
-                const uint32_t lz = v - t * ez;
-                const uint32_t lx = bk.ey > 1 ? __umulhi(t, my) : t;       // t / ey
-                const uint32_t ly = t - lx * bk.ey;
-                seg[v] = g0[(size_t)lx * gsx + (size_t)ly * gsy + lz];
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                const uint32_t v = lane + 64u * j;
+                if (v < vol) seg[v] = tmp[j];
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            (void)eyz;
         }
 
         // ---- march: up to K steps out of LDS ------------------------------------------------
         {
-            const uint32_t sy = bk.ez, sx = bk.ey * bk.ez;
-            const uint32_t ex1 = bk.ex - 1, ey1 = bk.ey - 1, ez1 = bk.ez - 1;
+            const uint32_t sy = ez, sx = ey * ez;
+            const uint32_t ex1 = bk.e[0] - 1, ey1 = ey - 1, ez1 = ez - 1;
+            const uint32_t lox = bk.lo[0], loy = bk.lo[1], loz = bk.lo[2];
             for (int k = 0; k < K; ++k) {
-                live = !done && it > 0 && in_field(r, bx1, by1, bz1);
-                if (!live) done = true;
-                const uint32_t cx = (r.px >> 16) - bk.lox, cy = (r.py >> 16) - bk.loy, cz = (r.pz >> 16) - bk.loz;
+                const uint32_t cx = (r.px >> 16) - lox, cy = (r.py >> 16) - loy, cz = (r.pz >> 16) - loz;
                 const bool inb = cx < ex1 && cy < ey1 && cz < ez1;   // cell and its +1 neighbours are staged
-                const unsigned long long lv = __ballot(live);
-                if (lv == 0ull) break;
-                if (__ballot(live && !inb) != 0ull) break;           // somebody left the brick: re-plan
-                if (live) {
+                bool want = !done && it > 0;
+                if (__ballot(want && !inb) != 0ull) {                // rare: some lane is outside the brick
+                    // the brick is clipped to the field, so a lane that left the field is outside it too: retire those
+                    if (want && !inb && !in_field(r, bx1, by1, bz1)) { done = true; want = false; }
+                    if (__ballot(want && !inb) != 0ull) { stat_add(p, kStatEarlyExit, 1); break; }   // a live ray left the brick: re-plan
+                }
+                if (__ballot(want) == 0ull) break;
+                stat_add(p, kStatLdsWaveSteps, 1);
+                if (want) {                                          // inside the brick => inside the field
                     f4 c[8];
-                    gather_lds<FieldT>(seg, (cx * bk.ey + cy) * bk.ez + cz, sy, sx, c);
+                    gather_lds<FieldT>(seg, (cx * ey + cy) * ez + cz, sy, sx, c);
                     if (march_step(r, c, invx, invy, invz)) done = true; else --it;
                 }
             }
@@ -201,15 +248,29 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock) void k_march_slab(const Ma
     if (have) store_ray<DirT>(p, ray, r, it);
 }
 
+template <typename FieldT, typename DirT, int VPL>
+hipError_t launch_slab_vpl(const MarchParams &p, hipStream_t s)
+{
+    using vox = typename FieldTraits<FieldT>::vox;
+    const unsigned threads = 64 * kSlabWavesPerBlock;
+    const unsigned grid = (p.nrays + threads - 1) / threads;
+    const size_t lds = sizeof(vox) * 64 * VPL * kSlabWavesPerBlock;
+    k_march_slab<FieldT, DirT, VPL><<<grid, threads, lds, s>>>(p);
+    return hipGetLastError();
+}
+
+// slab_lds_bytes selects the LDS segment per wave: 0 = default.
 template <typename FieldT, typename DirT>
 hipError_t launch_slab(MarchParams p, bool /*path*/, int /*num_cu*/, hipStream_t s)
 {
-    if (p.slab_lds_bytes == 0) p.slab_lds_bytes = 8192;
-    const unsigned threads = 64 * kSlabWavesPerBlock;
-    const unsigned grid = (p.nrays + threads - 1) / threads;
-    const size_t lds = (size_t)p.slab_lds_bytes * kSlabWavesPerBlock;
-    k_march_slab<FieldT, DirT><<<grid, threads, lds, s>>>(p);
-    return hipGetLastError();
+    using vox = typename FieldTraits<FieldT>::vox;
+    const uint32_t want = p.slab_lds_bytes ? p.slab_lds_bytes : 8192u;
+    const uint32_t vpl = want / (64u * (uint32_t)sizeof(vox));
+    if (vpl <= 4) return launch_slab_vpl<FieldT, DirT, 4>(p, s);
+    if (vpl <= 6) return launch_slab_vpl<FieldT, DirT, 6>(p, s);
+    if (vpl <= 8) return launch_slab_vpl<FieldT, DirT, 8>(p, s);
+    if (vpl <= 12) return launch_slab_vpl<FieldT, DirT, 12>(p, s);
+    return launch_slab_vpl<FieldT, DirT, 16>(p, s);
 }
 
 }  // namespace vrt

@@ -2,10 +2,15 @@
 //
 // The reference processes rays in caller order, one CUDA thread each
 // (/root/reference/src/cuda_volume_raytracer.cu:397-414).  On CDNA4 a 64-lane wavefront gathers
-// 8 voxels per lane per step, so which rays share a wavefront decides how many distinct
-// cache lines / LDS slab voxels one step touches.  This pass builds a permutation that puts
-// rays with the same dominant direction and neighbouring start voxels (3-D Morton order) next
-// to each other; kernels process slot i -> ray order[i] and write results back to the ray's
+// 8 voxels per lane per step, so which rays share a wavefront decides how many distinct cache
+// lines one gather touches (direct kernel) and how small the voxel brick is that the wavefront
+// has to stage in LDS (slab kernel).  This pass builds a permutation such that 64 consecutive
+// slots hold rays that (a) share the dominant direction, (b) start inside one square tile of
+// the plane orthogonal to it, the tile edge W chosen from the measured ray density so that a
+// tile holds about 64 rays, and (c) are ordered row-major inside the tile with the
+// memory-minor axis fastest, so the four lanes of a load quad fall into the same 128-byte line.
+// Tiles are visited in serpentine order so that a wavefront straddling two tiles still has
+// adjacent ones.  Kernels process slot i -> ray order[i] and write results back to the ray's
 // own index, so outputs are independent of the permutation.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -14,39 +19,84 @@
 
 namespace vrt {
 
-__device__ __forceinline__ uint64_t spread3(uint32_t v)   // 16 bits -> every third bit
+struct RayBounds {          // filled on the device, consumed on the device: no host round trip
+    uint32_t lo[3], hi[3];  // min / max start position per axis (16.16)
+};
+
+__global__ void k_bounds_init(RayBounds *b)
 {
-    uint64_t x = v & 0xFFFFu;
-    x = (x | (x << 32)) & 0x001F00000000FFFFull;
-    x = (x | (x << 16)) & 0x001F0000FF0000FFull;
-    x = (x | (x << 8))  & 0x100F00F00F00F00Full;
-    x = (x | (x << 4))  & 0x10C30C30C30C30C3ull;
-    x = (x | (x << 2))  & 0x1249249249249249ull;
-    return x;
+    if (threadIdx.x < 3) { b->lo[threadIdx.x] = 0xFFFFFFFFu; b->hi[threadIdx.x] = 0u; }
 }
 
+__global__ __launch_bounds__(256) void k_ray_bounds(const uint32_t *pos, uint32_t n, RayBounds *b)
+{
+    uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const uint32_t v = pos[3 * (size_t)i + d];
+            lo[d] = v < lo[d] ? v : lo[d];
+            hi[d] = v > hi[d] ? v : hi[d];
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t a = __shfl_xor(lo[d], o), c = __shfl_xor(hi[d], o);
+            lo[d] = a < lo[d] ? a : lo[d];
+            hi[d] = c > hi[d] ? c : hi[d];
+        }
+        if ((threadIdx.x & 63u) == 0) { atomicMin(&b->lo[d], lo[d]); atomicMax(&b->hi[d], hi[d]); }
+    }
+}
+
+// key layout, most significant first:
+//   dom:3 | depth bin:8 | tile u:11 | tile v (serpentine):11 | row inside tile:4 | v fine:27
 template <typename DirT>
 __global__ __launch_bounds__(256) void k_tile_keys(const uint32_t *pos, const DirT *dir, uint32_t n,
-                                                   uint64_t *keys, uint32_t *vals)
+                                                   const RayBounds *rb, uint64_t *keys, uint32_t *vals)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t x = pos[3 * (size_t)i] >> 16, y = pos[3 * (size_t)i + 1] >> 16, z = pos[3 * (size_t)i + 2] >> 16;
+    const uint32_t p[3] = {pos[3 * (size_t)i], pos[3 * (size_t)i + 1], pos[3 * (size_t)i + 2]};
     const float dx = (float)dir[3 * (size_t)i], dy = (float)dir[3 * (size_t)i + 1], dz = (float)dir[3 * (size_t)i + 2];
     const float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
+    // (w, u, v) = (dominant axis, slower orthogonal axis, faster orthogonal axis); z is memory-minor
+    int aw, au, av;
     uint32_t dom;
-    if (ax >= ay && ax >= az) dom = dx < 0 ? 1u : 0u;
-    else if (ay >= az)        dom = dy < 0 ? 3u : 2u;
-    else                      dom = dz < 0 ? 5u : 4u;
-    // z is the memory-minor axis: give it the lowest Morton bit so lane neighbours are address neighbours
-    keys[i] = ((uint64_t)dom << 48) | (spread3(x) << 2) | (spread3(y) << 1) | spread3(z);
+    if (ax >= ay && ax >= az) { aw = 0; au = 1; av = 2; dom = dx < 0 ? 1u : 0u; }
+    else if (ay >= az)        { aw = 1; au = 0; av = 2; dom = dy < 0 ? 3u : 2u; }
+    else                      { aw = 2; au = 0; av = 1; dom = dz < 0 ? 5u : 4u; }
+    const float ru = (float)(rb->hi[au] - rb->lo[au]) + 1.0f, rv = (float)(rb->hi[av] - rb->lo[av]) + 1.0f;
+    const float rw = (float)(rb->hi[aw] - rb->lo[aw]) + 1.0f;
+    // tile edge W (16.16 units): W^2 * (n / (ru*rv)) = 64 rays; if the rays fill a volume rather
+    // than a sheet, depth bins of the same size thin the density by rw/W -- one fixed-point
+    // refinement step is enough for a grouping heuristic.
+    float W = sqrtf(64.0f * ru * rv / (float)n);
+    if (rw > 2.0f * W) W = cbrtf(64.0f * ru * rv * rw / (float)n);
+    W = fminf(fmaxf(W, 4096.0f), 64.0f * 65536.0f);
+    W = fmaxf(W, fmaxf(ru, rv) / 2040.0f);                       // at most 2047 tiles per axis
+    const float invW = 1.0f / W;
+    const float fu = (float)(p[au] - rb->lo[au]) * invW, fv = (float)(p[av] - rb->lo[av]) * invW;
+    uint32_t tu = (uint32_t)fu, tv = (uint32_t)fv;
+    tu = tu > 2047u ? 2047u : tu;
+    tv = tv > 2047u ? 2047u : tv;
+    uint32_t row = (uint32_t)((fu - (float)tu) * 16.0f);
+    row = row > 15u ? 15u : row;
+    uint32_t wb = (uint32_t)((float)(p[aw] - rb->lo[aw]) * fminf(invW, 255.0f / rw));
+    wb = wb > 255u ? 255u : wb;
+    uint32_t vf = (p[av] - rb->lo[av]) >> 5;
+    vf = vf > 0x7FFFFFFu ? 0x7FFFFFFu : vf;
+    if (tu & 1u) { tv = 2047u - tv; vf = 0x7FFFFFFu - vf; }      // serpentine: odd tile columns run backwards
+    keys[i] = ((uint64_t)dom << 61) | ((uint64_t)wb << 53) | ((uint64_t)tu << 42) | ((uint64_t)tv << 31) |
+              ((uint64_t)row << 27) | (uint64_t)vf;
     vals[i] = i;
 }
 
 // grow-only device buffer interface expected from the caller (see DevBuf in vrt_engine.hip)
 template <typename Buf>
 hipError_t build_tile_order(const uint32_t *d_pos, const void *d_dir, int dir_is_i16, uint32_t n, Buf &keys,
-                            Buf &keys_alt, Buf &vals, Buf &vals_alt, Buf &tmp, hipStream_t s,
+                            Buf &keys_alt, Buf &vals, Buf &vals_alt, Buf &tmp, Buf &bounds, hipStream_t s,
                             const uint32_t **order_out)
 {
     hipError_t e;
@@ -54,17 +104,22 @@ hipError_t build_tile_order(const uint32_t *d_pos, const void *d_dir, int dir_is
     if ((e = keys_alt.reserve((size_t)n * 8)) != hipSuccess) return e;
     if ((e = vals.reserve((size_t)n * 4)) != hipSuccess) return e;
     if ((e = vals_alt.reserve((size_t)n * 4)) != hipSuccess) return e;
+    if ((e = bounds.reserve(sizeof(RayBounds))) != hipSuccess) return e;
+    RayBounds *rb = (RayBounds *)bounds.p;
+    k_bounds_init<<<1, 64, 0, s>>>(rb);
+    const unsigned rgrid = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    k_ray_bounds<<<rgrid, 256, 0, s>>>(d_pos, n, rb);
     const unsigned grid = (n + 255) / 256;
-    if (dir_is_i16) k_tile_keys<int16_t><<<grid, 256, 0, s>>>(d_pos, (const int16_t *)d_dir, n, (uint64_t *)keys.p, (uint32_t *)vals.p);
-    else            k_tile_keys<float><<<grid, 256, 0, s>>>(d_pos, (const float *)d_dir, n, (uint64_t *)keys.p, (uint32_t *)vals.p);
+    if (dir_is_i16) k_tile_keys<int16_t><<<grid, 256, 0, s>>>(d_pos, (const int16_t *)d_dir, n, rb, (uint64_t *)keys.p, (uint32_t *)vals.p);
+    else            k_tile_keys<float><<<grid, 256, 0, s>>>(d_pos, (const float *)d_dir, n, rb, (uint64_t *)keys.p, (uint32_t *)vals.p);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     size_t tmp_bytes = 0;
     e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const uint64_t *)keys.p, (uint64_t *)keys_alt.p,
-                                  (const uint32_t *)vals.p, (uint32_t *)vals_alt.p, n, 0, 51, s);
+                                  (const uint32_t *)vals.p, (uint32_t *)vals_alt.p, n, 0, 64, s);
     if (e != hipSuccess) return e;
     if ((e = tmp.reserve(tmp_bytes ? tmp_bytes : 16)) != hipSuccess) return e;
     e = rocprim::radix_sort_pairs(tmp.p, tmp_bytes, (const uint64_t *)keys.p, (uint64_t *)keys_alt.p,
-                                  (const uint32_t *)vals.p, (uint32_t *)vals_alt.p, n, 0, 51, s);
+                                  (const uint32_t *)vals.p, (uint32_t *)vals_alt.p, n, 0, 64, s);
     if (e != hipSuccess) return e;
     *order_out = (const uint32_t *)vals_alt.p;
     return hipSuccess;
