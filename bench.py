@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from volumeraytracer_amd import capi, workloads as W  # noqa: E402
+from volumeraytracer_amd import capi, distributed as D, workloads as W  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 
@@ -85,8 +85,8 @@ def synth_field_device(N, field, dev, opaque=False, seed=1234, nblobs=4, amp=0.5
 def make_rays(cfg, rank, world):
     gen = W.perspective_rays if cfg["gen"] == "perspective" else W.ortho_rays
     R = cfg["R"]
-    # weak scaling: a (R*world) x R lattice, rank r marches rows [r*R, (r+1)*R)
-    return gen(cfg["N"], R, rows_total=R * world, row_range=(rank * R, (rank + 1) * R))
+    # weak scaling: a (R*world) x R lattice, rank r marches one contiguous band of R rows
+    return gen(cfg["N"], R, rows_total=R * world, row_range=D.row_band(R * world, rank, world))
 
 
 def cpu_baseline(field_host, bounds, sp, sd, inv, iterations, gpu_out, budget_s, log):
@@ -95,8 +95,8 @@ def cpu_baseline(field_host, bounds, sp, sd, inv, iterations, gpu_out, budget_s,
     n = sp.size // 3
     sp3, sd3 = sp.reshape(-1, 3), sd.reshape(-1, 3)
     threads = oracle.port.num_threads()
-    # calibrate on 1024 evenly spread rays
-    idx = np.linspace(0, n - 1, min(n, 1024)).astype(np.int64)
+    # calibrate on 16384 evenly spread rays (enough work for every thread)
+    idx = np.linspace(0, n - 1, min(n, 16384)).astype(np.int64)
     t0 = time.time()
     out = oracle.port.trace(field_host, bounds, sp3[idx].reshape(-1), sd3[idx].reshape(-1), inv, iterations)
     dt = max(time.time() - t0, 1e-4)
@@ -167,9 +167,9 @@ def main():
     d_sp = torch.from_numpy(sp.view(np.int32)).to(dev)
     d_sd = torch.from_numpy(sd).to(dev)
     # one contiguous output record per rank: [end_pos 3n | end_dir 3n | end_iter n | light n] (32 B/ray)
-    out = torch.empty(8 * n, dtype=torch.int32, device=dev)
-    o_ep, o_ed, o_ei, o_rl = out[0:3 * n], out[3 * n:6 * n], out[6 * n:7 * n], out[7 * n:8 * n]
-    gathered = [torch.empty_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
+    out = D.alloc_record(n, dev)
+    o_ep, o_ed, o_ei, o_rl = D.record_views(out, n)
+    counts = [n] * world
     inv = [1.0, 1.0, 1.0]
     kern = {"auto": capi.KERNEL_AUTO, "direct": capi.KERNEL_DIRECT, "slab": capi.KERNEL_SLAB}[args.kernel]
     opts = capi.default_options(kernel=kern, sort_rays=args.sort, slab_lds_bytes=args.lds_bytes)
@@ -179,7 +179,7 @@ def main():
         eng.trace_device(capi.VRT_F32, n, d_sp.data_ptr(), d_sd.data_ptr(), o_ep.data_ptr(), o_ed.data_ptr(),
                          o_ei.data_ptr(), o_rl.data_ptr(), inv, args.iterations, stream=stream, options=opts)
         if world > 1:
-            dist.gather(out, gathered, dst=0)
+            D.gather_records(out, counts, dst=0)
 
     for _ in range(args.warmup):
         step()

@@ -1,0 +1,91 @@
+"""CPU, world_size 2 over gloo: the N > 1 path of bench.py -- ray sharding into contiguous bands,
+per-rank output records, gather to rank 0, reassembly in global ray order.  The march itself is
+GPU-only, so each rank's record is filled by the oracle (tests may use it); what is under test is
+the partition + collective + ordering logic that runs unchanged over RCCL on the GPUs."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from volumeraytracer_amd import distributed as D, workloads as W
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, N, R, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        bounds, dx, dy, dz, tc = W.seam_field(N, np.float32)
+        field = oracle.port.interleave(dx, dy, dz, tc)
+        rows = R * world
+        r0, r1 = D.row_band(rows, rank, world)
+        sp, sd = W.perspective_rays(N, R, rows_total=rows, row_range=(r0, r1))
+        if rank == 1:                      # uneven shards: rank 1 drops its last 5 rays
+            sp, sd = sp[:-15], sd[:-15]
+        n = sp.size // 3
+        out = oracle.port.trace(field, bounds, sp, sd, [1, 1, 1], 100000, nthreads=2)
+        rec = D.alloc_record(n, "cpu")
+        ep, ed, ei, rl = D.record_views(rec, n)
+        ep.copy_(torch.from_numpy(out["end_position"].view(np.int32)))
+        ed.copy_(torch.from_numpy(out["end_direction"].view(np.int32)))
+        ei.copy_(torch.from_numpy(out["end_iteration"].view(np.int32)))
+        rl.copy_(torch.from_numpy(out["remaining_light"].view(np.int32)))
+        counts = [None] * world
+        dist.all_gather_object(counts, n)
+        recs = D.gather_records(rec, counts, dst=0)
+        if rank == 0:
+            whole = D.assemble(recs, counts)
+            q.put({k: v for k, v in whole.items()})
+        else:
+            assert recs is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gather_matches_single_process():
+    N, R, world = 32, 24, 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, R, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    # single-process answer on the same global ray set (rank 1's last 5 rays dropped)
+    bounds, dx, dy, dz, tc = W.seam_field(N, np.float32)
+    field = oracle.port.interleave(dx, dy, dz, tc)
+    sp, sd = W.perspective_rays(N, R, rows_total=R * world)
+    sp, sd = sp[:-15], sd[:-15]
+    want = oracle.port.trace(field, bounds, sp, sd, [1, 1, 1], 100000)
+    assert np.array_equal(got["end_position"], want["end_position"])
+    assert np.array_equal(got["end_direction_bits"], want["end_direction"].view(np.uint32))
+    assert np.array_equal(got["end_iteration"], want["end_iteration"])
+    assert np.all(got["remaining_light"] == 0xFFFFFFFF)
+
+
+def test_ray_range_partition():
+    for n in (0, 1, 7, 64, 1000, 1048576):
+        for world in (1, 2, 3, 8):
+            ranges = [D.ray_range(n, r, world) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == n
+            for a, b in zip(ranges, ranges[1:]):
+                assert a[1] == b[0]
+            sizes = [e - b for b, e in ranges]
+            assert max(sizes) - min(sizes) <= 1

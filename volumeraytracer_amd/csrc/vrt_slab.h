@@ -98,8 +98,9 @@ __device__ __forceinline__ void gather_lds(const typename FieldTraits<FieldT>::v
 }
 
 // VPL = voxels staged per lane at most; the wave's LDS segment holds 64*VPL voxels.
-template <typename FieldT, typename DirT, int VPL>
-__global__ __launch_bounds__(64 * kSlabWavesPerBlock) void k_march_slab(const MarchParams p)
+// OCC = waves per SIMD the register allocator must allow (launch-bounds second argument).
+template <typename FieldT, typename DirT, int VPL, int OCC>
+__global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(const MarchParams p)
 {
     using vox = typename FieldTraits<FieldT>::vox;
     constexpr uint32_t kCap = 64u * VPL;
@@ -248,14 +249,14 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock) void k_march_slab(const Ma
     if (have) store_ray<DirT>(p, ray, r, it);
 }
 
-template <typename FieldT, typename DirT, int VPL>
+template <typename FieldT, typename DirT, int VPL, int OCC>
 hipError_t launch_slab_vpl(const MarchParams &p, hipStream_t s)
 {
     using vox = typename FieldTraits<FieldT>::vox;
     const unsigned threads = 64 * kSlabWavesPerBlock;
     const unsigned grid = (p.nrays + threads - 1) / threads;
     const size_t lds = sizeof(vox) * 64 * VPL * kSlabWavesPerBlock;
-    k_march_slab<FieldT, DirT, VPL><<<grid, threads, lds, s>>>(p);
+    k_march_slab<FieldT, DirT, VPL, OCC><<<grid, threads, lds, s>>>(p);
     return hipGetLastError();
 }
 
@@ -264,13 +265,15 @@ template <typename FieldT, typename DirT>
 hipError_t launch_slab(MarchParams p, bool /*path*/, int /*num_cu*/, hipStream_t s)
 {
     using vox = typename FieldTraits<FieldT>::vox;
-    const uint32_t want = p.slab_lds_bytes ? p.slab_lds_bytes : 8192u;
+    const uint32_t want = p.slab_lds_bytes ? p.slab_lds_bytes : 6144u;   // measured best on config 3
     const uint32_t vpl = want / (64u * (uint32_t)sizeof(vox));
-    if (vpl <= 4) return launch_slab_vpl<FieldT, DirT, 4>(p, s);
-    if (vpl <= 6) return launch_slab_vpl<FieldT, DirT, 6>(p, s);
-    if (vpl <= 8) return launch_slab_vpl<FieldT, DirT, 8>(p, s);
-    if (vpl <= 12) return launch_slab_vpl<FieldT, DirT, 12>(p, s);
-    return launch_slab_vpl<FieldT, DirT, 16>(p, s);
+    // LDS per wave and register budget are chosen together: 160 KiB LDS / CU and 512 VGPRs / SIMD lane
+    if (vpl <= 4) return launch_slab_vpl<FieldT, DirT, 4, 8>(p, s);
+    if (vpl <= 5) return launch_slab_vpl<FieldT, DirT, 5, 8>(p, s);
+    if (vpl <= 6) return launch_slab_vpl<FieldT, DirT, 6, 6>(p, s);
+    if (vpl <= 8) return launch_slab_vpl<FieldT, DirT, 8, 5>(p, s);
+    if (vpl <= 12) return launch_slab_vpl<FieldT, DirT, 12, 3>(p, s);
+    return launch_slab_vpl<FieldT, DirT, 16, 2>(p, s);
 }
 
 }  // namespace vrt

@@ -1,0 +1,71 @@
+"""Multi-GPU plumbing for trace_rays: one process per GPU, field replicated, rays sharded.
+
+The reference's multi-device strategy is an OpenMP thread per CUDA device pulling 0x8000-ray
+chunks, with the field replicated and every result copied back through host memory
+(/root/reference/src/cuda_volume_raytracer.cu:676-686, 804-912); it has no collective.  Rays are
+independent and the field is read-only, so here each rank owns a contiguous range of rays (row
+bands of the ray lattice keep entry tiles coherent), marches them with its own engine, and the
+per-ray output records (32 B/ray) are gathered to rank 0 with one torch.distributed gather --
+RCCL over xGMI with backend "nccl", gloo on CPU for the tests.  No other exchange exists on the
+path.
+"""
+import numpy as np
+import torch
+
+RECORD_WORDS = 8   # end_pos 3 + end_dir 3 + end_iter 1 + remaining_light 1 (32-bit words per ray)
+
+
+def ray_range(nrays, rank, world):
+    """Contiguous, balanced range [begin, end) of rays owned by `rank` (first ranks take the remainder)."""
+    base, rem = divmod(int(nrays), int(world))
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def row_band(rows_total, rank, world):
+    """Contiguous band of lattice rows owned by `rank` (whole rows keep a rank's rays a compact slab)."""
+    return ray_range(rows_total, rank, world)
+
+
+def record_views(buf, n):
+    """Views into one rank's contiguous output record [end_pos 3n | end_dir 3n | end_iter n | light n]
+    (int32 storage; end_dir holds float32 or int16-widened bits as written by the engine)."""
+    assert buf.numel() == RECORD_WORDS * n
+    return buf[0:3 * n], buf[3 * n:6 * n], buf[6 * n:7 * n], buf[7 * n:8 * n]
+
+
+def alloc_record(n, device):
+    return torch.empty(RECORD_WORDS * n, dtype=torch.int32, device=device)
+
+
+def gather_records(local, counts, dst=0, group=None):
+    """Gather every rank's record to `dst`.  `counts[r]` = number of rays of rank r.  Ranks may own
+    different counts: records are padded to the largest one for the collective and trimmed on dst.
+    Returns the list of per-rank records on dst, None elsewhere."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    nmax = max(counts)
+    send = local
+    if local.numel() != RECORD_WORDS * nmax:
+        send = torch.zeros(RECORD_WORDS * nmax, dtype=local.dtype, device=local.device)
+        send[:local.numel()] = local
+    recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, recv, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return [recv[r][:RECORD_WORDS * counts[r]] for r in range(world)]
+
+
+def assemble(records, counts):
+    """dst side: concatenate per-rank records back into whole-job arrays in global ray order
+    (rank r's rays precede rank r+1's).  Returns dict of numpy arrays (bit patterns, uint32)."""
+    ep, ed, ei, rl = [], [], [], []
+    for rec, n in zip(records, counts):
+        a, b, c, d = record_views(rec, n)
+        ep.append(a.cpu().numpy().view(np.uint32))
+        ed.append(b.cpu().numpy().view(np.uint32))
+        ei.append(c.cpu().numpy().view(np.uint32))
+        rl.append(d.cpu().numpy().view(np.uint32))
+    return dict(end_position=np.concatenate(ep), end_direction_bits=np.concatenate(ed),
+                end_iteration=np.concatenate(ei), remaining_light=np.concatenate(rl))
