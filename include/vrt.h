@@ -147,6 +147,47 @@ float vrt_engine_last_march_ms(vrt_handle h);
  * rounds / staged voxels / LDS steps; this copies up to n (<= 64) counters of the last launch. */
 int vrt_engine_debug_stats(vrt_handle h, unsigned long long *out, int n);
 
+/* ---------------------------------------------------------------------------------------------
+ * Scene layer: the reference's RaytraceScene<Ior,IorLog,Diff>
+ * (image_util.h:132-195), i.e. what python_binding.cpp:38 and java_binding.cpp:179-287 call.
+ * Instantiations as in the reference (image_util.cpp:940-956):
+ *   ior_type VRT_F32: float ior, fp32 field, float directions only
+ *   ior_type VRT_U32: ior_t 16.16 fixed, int16 field, int16 (8.8) directions only
+ * --------------------------------------------------------------------------------------------- */
+#define VRT_U32 2
+
+typedef struct vrt_scene *vrt_scene_handle;
+
+/*
+ * Replaces RaytraceScene::RaytraceScene(bound_vec, ior, translucency, opt) (image_util.cpp:501-643):
+ * size checks, translucency crop, ior_log = log(ior)*0x420000 (host libm, as the reference),
+ * 3x3x3 derivative stencil + interleave on the device, engine creation.
+ *   bounds[dim]  volume extents (the field is bounds-2); dim must be 3
+ *   ior, translucency  HOST pointers, nvox elements
+ * Errors: VRT_ERR_SCENE with the reference's message ("imagesizes doesn't match...",
+ * "refraction-index underflow...", "differention overflow...").
+ */
+int vrt_scene_create(vrt_scene_handle *out, int dim, const size_t *bounds, int ior_type, const void *ior,
+                     const uint32_t *translucency, size_t nvox, const vrt_options *opt);
+
+/*
+ * Replaces RaytraceScene::trace_rays<DirType>(...) (image_util.cpp:645-772): range check
+ * (VRT_ERR_RAY_RANGE, "ray i:... is not in 0 to ..."), -0x8000 shift, ior interpolation, direction
+ * normalisation (always on, as the reference's "normalize_length || true"), second shift, the march,
+ * and the +0x10000 epilogue on end_pos and path.  Positions are in VOLUME coordinates.
+ * HOST pointers; dir_type must match the scene's family.
+ */
+int vrt_scene_trace(vrt_scene_handle s, int dir_type, size_t nrays, const uint32_t *start_pos, const void *start_dir,
+                    uint32_t *end_pos, void *end_dir, uint32_t *end_iter, uint32_t *remaining_light,
+                    uint32_t *path, const float *invscale, uint32_t min_brightness, uint32_t iterations,
+                    int normalize_length, const vrt_options *opt);
+
+/* Replaces RaytraceScene::~RaytraceScene (image_util.cpp:774-778). */
+void vrt_scene_destroy(vrt_scene_handle s);
+
+/* The seam-level engine inside a scene (owned by the scene). */
+vrt_handle vrt_scene_engine(vrt_scene_handle s);
+
 /* Message of the last failure on this thread ("" if none).  Valid until the next failing call. */
 const char *vrt_last_error(void);
 

@@ -4,6 +4,6 @@ Compute happens only in the HIP library behind include/vrt.h (volumeraytracer_am
 there is no CPU fallback.  See DESIGN.md / INTEGRATION.md.
 """
 from . import capi, workloads  # noqa: F401
-from .capi import Engine, Options, VrtError, default_options, device_count  # noqa: F401
+from .capi import Engine, Options, Scene, VrtError, default_options, device_count  # noqa: F401
 
-__all__ = ["capi", "workloads", "Engine", "Options", "VrtError", "default_options", "device_count"]
+__all__ = ["capi", "workloads", "Engine", "Scene", "Options", "VrtError", "default_options", "device_count"]

@@ -11,7 +11,7 @@ import numpy as np
 
 from . import _build
 
-VRT_F32, VRT_I16 = 0, 1
+VRT_F32, VRT_I16, VRT_U32 = 0, 1, 2
 KERNEL_AUTO, KERNEL_DIRECT, KERNEL_SLAB = 0, 1, 2
 
 # every symbol include/vrt.h declares (checked by tests/test_abi.py against the header text)
@@ -19,7 +19,7 @@ ABI_SYMBOLS = (
     "vrt_options_default", "vrt_device_count", "vrt_abi_version", "vrt_create", "vrt_create_from_device",
     "vrt_trace", "vrt_trace_device", "vrt_destroy", "vrt_engine_device", "vrt_engine_field_bytes",
     "vrt_engine_field_device_ptr", "vrt_engine_last_march_ms", "vrt_engine_debug_stats",
-    "vrt_last_error",
+    "vrt_last_error", "vrt_scene_create", "vrt_scene_trace", "vrt_scene_destroy", "vrt_scene_engine",
 )
 
 
@@ -87,7 +87,8 @@ def load():
     L.vrt_engine_last_march_ms.argtypes = [vp]
     L.vrt_engine_last_march_ms.restype = C.c_float
     if hasattr(L, "vrt_scene_create"):
-        L.vrt_scene_create.argtypes = [C.POINTER(vp), C.c_int, vp, C.c_int, vp, u32p, sz, C.POINTER(Options)]
+        L.vrt_scene_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_size_t), C.c_int, vp, u32p, sz,
+                                       C.POINTER(Options)]
         L.vrt_scene_trace.argtypes = [vp, C.c_int, sz, u32p, vp, u32p, vp, u32p, u32p, u32p, vp, C.c_uint32,
                                       C.c_uint32, C.c_int, C.POINTER(Options)]
         L.vrt_scene_destroy.argtypes = [vp]
@@ -223,6 +224,70 @@ class Engine:
     def close(self):
         if self._h is not None and _lib is not None:
             _lib.vrt_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+class Scene:
+    """Owning handle on a vrt_scene == the reference's RaytraceScene<Ior,IorLog,Diff>
+    (image_util.h:132-195): ior volume -> derivative field on the GPU; trace_rays with the ray
+    front end (range check, ior normalisation, coordinate shifts) on the GPU."""
+
+    def __init__(self, bounds, ior, translucency, options=None):
+        L = load()
+        ior = np.ascontiguousarray(ior).reshape(-1)
+        if ior.dtype == np.float32:
+            self.ior_type = VRT_F32
+        else:
+            ior = np.ascontiguousarray(ior, dtype=np.uint32)
+            self.ior_type = VRT_U32
+        tr = np.ascontiguousarray(translucency, dtype=np.uint32).reshape(-1)
+        if tr.size != ior.size:
+            raise VrtError(-6, "imagesizes doesn't match:%d=%d=%d (bounds ior translucency)"
+                           % (int(np.prod([int(b) for b in bounds])), ior.size, tr.size))
+        b = (C.c_size_t * len(bounds))(*[int(x) for x in bounds])
+        h = C.c_void_p()
+        check(L.vrt_scene_create(C.byref(h), len(bounds), b, self.ior_type, _np_ptr(ior), _np_ptr(tr), ior.size,
+                                 C.byref(options) if options is not None else None))
+        self._h = h
+        self.bounds = [int(x) for x in bounds]
+
+    def trace_rays(self, start_position, start_direction, invscale, iterations, trace_paths=False,
+                   minimum_brightness=0, normalize_length=True, options=None):
+        L = load()
+        sd = np.ascontiguousarray(start_direction).reshape(-1)
+        dt = _type_of(sd.dtype)
+        sp = np.ascontiguousarray(start_position, dtype=np.uint32).reshape(-1)
+        if sp.size != sd.size or sp.size % 3:
+            raise VrtError(-1, "raycounts doesn't match, dimension is: 3 raysizes are start_position: %d "
+                               "start_direction: %d" % (sp.size, sd.size))      # image_util.cpp:664-667
+        n = sp.size // 3
+        inv = np.ascontiguousarray(invscale, dtype=np.float32)
+        ep = np.empty(3 * n, np.uint32)
+        ed = np.empty(3 * n, sd.dtype)
+        ei = np.empty(n, np.uint32)
+        rl = np.empty(n, np.uint32)
+        path = np.empty(int(iterations) * 3 * n, np.uint32) if trace_paths else None
+        check(L.vrt_scene_trace(self._h, dt, n, _np_ptr(sp), _np_ptr(sd), _np_ptr(ep), _np_ptr(ed), _np_ptr(ei),
+                                _np_ptr(rl), _np_ptr(path) if path is not None else None, _np_ptr(inv),
+                                int(minimum_brightness), int(iterations), 1 if normalize_length else 0,
+                                C.byref(options) if options is not None else None))
+        return dict(end_position=ep, end_direction=ed, end_iteration=ei, remaining_light=rl, path=path)
+
+    def close(self):
+        if self._h is not None and _lib is not None:
+            _lib.vrt_scene_destroy(self._h)
         self._h = None
 
     def __del__(self):

@@ -22,6 +22,12 @@
 #include "vrt_march.h"
 #include "vrt_slab.h"
 #include "vrt_sort.h"
+#include "vrt_scene.h"
+
+#include <cmath>
+#include <thread>
+#include <vector>
+#include <atomic>
 
 namespace {
 
@@ -227,7 +233,8 @@ int launch_typed(vrt_engine *e, const vrt::MarchParams &p, int kernel, hipStream
 
 int trace_device_impl(vrt_engine *e, int dir_type, size_t nrays, const uint32_t *d_sp, const void *d_sd,
                       uint32_t *d_ep, void *d_ed, uint32_t *d_ei, uint32_t *d_rl, uint32_t *d_path,
-                      const float *invscale, uint32_t iterations, hipStream_t s, const vrt_options *opt)
+                      const float *invscale, uint32_t iterations, hipStream_t s, const vrt_options *opt,
+                      uint32_t out_pos_bias = 0)
 {
     if (nrays == 0) return VRT_OK;
     const vrt_options &o = opt ? *opt : e->opt;
@@ -241,6 +248,7 @@ int trace_device_impl(vrt_engine *e, int dir_type, size_t nrays, const uint32_t 
     p.order = nullptr;
     p.iterations = iterations;
     p.nrays = (uint32_t)nrays;
+    p.out_pos_bias = out_pos_bias;
     p.slab_lds_bytes = 0;
     if (o.slab_lds_bytes > 0) {
         if (o.slab_lds_bytes < 1024 || o.slab_lds_bytes > 40960 || (o.slab_lds_bytes & 15))
@@ -299,7 +307,88 @@ int check_trace_args(vrt_handle h, int dir_type, size_t nrays, const void *sp, c
     return VRT_OK;
 }
 
+// Host-pointer trace shared by vrt_trace and vrt_scene_trace.  `pre` (optional) rewrites the
+// uploaded start arrays on the device before the march (the scene layer's ray prologue).
+template <typename Pre>
+int trace_host_impl(vrt_engine *e, int dir_type, size_t nrays, const uint32_t *sp, const void *sd, uint32_t *ep,
+                    void *ed, uint32_t *ei, uint32_t *rl, uint32_t *path, const float *invscale, uint32_t iterations,
+                    const vrt_options *opt, uint32_t out_pos_bias, Pre pre)
+{
+    const vrt_options &o = opt ? *opt : e->opt;
+    const size_t dsz = dir_type == VRT_F32 ? 4 : 2;
+    hipStream_t s = e->stream;
+    // Rays go up in one piece when no path is requested; with path tracing the device path
+    // buffer (iterations*12 bytes per ray) bounds the chunk, as the reference's 0x8000-ray
+    // chunks bound its own (.cu:798, 840).
+    size_t chunk = nrays;
+    if (path) {
+        const size_t per_ray = (size_t)iterations * 12;
+        const size_t budget = (size_t)2 << 30;
+        chunk = std::max<size_t>(1, std::min(nrays, budget / std::max<size_t>(per_ray, 1)));
+    }
+    HIP_TRY(e->h_in_pos.reserve(chunk * 12));
+    HIP_TRY(e->h_in_dir.reserve(chunk * 3 * dsz));
+    HIP_TRY(e->h_out_pos.reserve(chunk * 12));
+    HIP_TRY(e->h_out_dir.reserve(chunk * 3 * dsz));
+    HIP_TRY(e->h_out_iter.reserve(chunk * 4));
+    HIP_TRY(e->h_out_light.reserve(chunk * 4));
+    if (path) HIP_TRY(e->h_path.reserve(chunk * (size_t)iterations * 12));
+
+    const size_t nchunks = (nrays + chunk - 1) / chunk;
+    bool cap_hit = false;
+    for (size_t c = 0, off = 0; off < nrays; ++c, off += chunk) {
+        const size_t n = std::min(chunk, nrays - off);
+        if (o.loglevel < 0) printf("iteration %zu of %zu\n", c, nchunks);          // .cu:823-826
+        HIP_TRY(hipMemcpyAsync(e->h_in_pos.p, sp + 3 * off, n * 12, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(e->h_in_dir.p, (const char *)sd + 3 * off * dsz, n * 3 * dsz, hipMemcpyHostToDevice, s));
+        int rc = pre((uint32_t *)e->h_in_pos.p, e->h_in_dir.p, n, off, s);
+        if (rc) return rc;
+        rc = trace_device_impl(e, dir_type, n, (const uint32_t *)e->h_in_pos.p, e->h_in_dir.p,
+                               (uint32_t *)e->h_out_pos.p, e->h_out_dir.p, (uint32_t *)e->h_out_iter.p,
+                               (uint32_t *)e->h_out_light.p, path ? (uint32_t *)e->h_path.p : nullptr, invscale,
+                               iterations, s, opt, out_pos_bias);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(ep + 3 * off, e->h_out_pos.p, n * 12, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync((char *)ed + 3 * off * dsz, e->h_out_dir.p, n * 3 * dsz, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(ei + off, e->h_out_iter.p, n * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(rl + off, e->h_out_light.p, n * 4, hipMemcpyDeviceToHost, s));
+        if (path)
+            HIP_TRY(hipMemcpyAsync(path + off * (size_t)iterations * 3, e->h_path.p, n * (size_t)iterations * 12,
+                                   hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    for (size_t i = 0; i < nrays && !cap_hit; ++i) cap_hit = (ei[i] == iterations);
+    if (cap_hit) printf("Warning, maximum iterations hitted\n");                   // .cu:512-515
+    if (o.loglevel < 0) printf("cpu: 0 gpu: %zu\n", nchunks);                      // .cu:948-951
+    return VRT_OK;
+}
+
+// parallel-for over [0, n) on the host (the log pass of the scene build)
+template <typename F>
+void host_parallel_for(size_t n, F f)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt == 0 ? 1 : (nt > 64 ? 64 : nt);
+    if (n < 65536 || nt == 1) { f(0, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; ++t) {
+        const size_t b = std::min(n, (size_t)t * per), e2 = std::min(n, b + per);
+        if (b < e2) th.emplace_back([=] { f(b, e2); });
+    }
+    for (auto &x : th) x.join();
+}
+
 }  // namespace
+
+struct vrt_scene {
+    vrt_engine *engine = nullptr;
+    int ior_type = VRT_F32;
+    uint32_t N[3] = {0, 0, 0};
+    void *d_ior = nullptr;          // the ior volume stays resident for the ray prologue's interpolation
+    void *d_err = nullptr;          // vrt::SceneErr
+    DevBuf pro_pos, pro_dir;
+};
 
 // =============================================================================================
 // C ABI
@@ -406,55 +495,171 @@ int vrt_trace(vrt_handle h, int dir_type, size_t nrays, const uint32_t *sp, cons
     int rc = check_trace_args(h, dir_type, nrays, sp, sd, ep, ed, ei, rl, invscale, iterations);
     if (rc) return rc;
     if (nrays == 0) return VRT_OK;
-    vrt_engine *e = h;
+    DeviceGuard g(h->device);
+    return trace_host_impl(h, dir_type, nrays, sp, sd, ep, ed, ei, rl, path, invscale, iterations, opt, 0,
+                           [](uint32_t *, void *, size_t, size_t, hipStream_t) { return (int)VRT_OK; });
+}
+
+// ---- scene layer ---------------------------------------------------------------------------
+
+int vrt_scene_create(vrt_scene_handle *out, int dim, const size_t *bounds, int ior_type, const void *ior,
+                     const uint32_t *translucency, size_t nvox, const vrt_options *opt)
+{
+    if (!out) return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_scene_create: out is NULL");
+    *out = nullptr;
+    if (dim == 0) return fail(VRT_ERR_SCENE, "dimension is zero");                                  // image_util.cpp:508-511
+    if (dim != 3) return fail(VRT_ERR_ILLEGAL_DIMENSION, "Illegal dimension: %d", dim);             // :559
+    if (!bounds || !ior || !translucency) return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_scene_create: NULL argument");
+    if (ior_type != VRT_F32 && ior_type != VRT_U32)
+        return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_scene_create: ior_type must be VRT_F32 or VRT_U32");
+    const size_t prod = bounds[0] * bounds[1] * bounds[2];
+    if (prod != nvox)                                                                               // :512-515
+        return fail(VRT_ERR_SCENE, "imagesizes doesn't match:%zu=%zu=%zu (bounds ior translucency)", prod, nvox, nvox);
+    for (int d = 0; d < 3; ++d)
+        if (bounds[d] < 3 || bounds[d] > 65535)
+            return fail(VRT_ERR_SCENE, "bounds[%d] = %zu: the 3x3x3 stencil needs 3 <= extent <= 65535", d, bounds[d]);
+
+    // ior_log on the host with the libm the reference itself calls (image_util.cpp:531-543, 605-611)
+    std::vector<uint32_t> lg(nvox);                     // float or int32 bit patterns
+    std::atomic<int> bad{0};
+    if (ior_type == VRT_F32) {
+        const float *f = (const float *)ior;
+        host_parallel_for(nvox, [&](size_t b, size_t e2) {
+            for (size_t i = b; i < e2; ++i) {
+                if (f[i] <= 0) { bad.store(1); continue; }
+                const float v = (float)(std::log((double)f[i]) * (double)0x420000);
+                memcpy(&lg[i], &v, 4);
+            }
+        });
+        if (bad.load()) return fail(VRT_ERR_SCENE, "refraction-index underflow: ior <= 0");
+    } else {
+        const uint32_t *u = (const uint32_t *)ior;
+        host_parallel_for(nvox, [&](size_t b, size_t e2) {
+            for (size_t i = b; i < e2; ++i) {
+                const double tmp = std::log((double)u[i] / 65536.0) * (double)0x420000;
+                if (tmp > 2147483647.0) { bad.store(1); continue; }
+                if (tmp < -2147483648.0) { bad.store(2); continue; }
+                const int32_t v = (int32_t)std::round(tmp);
+                memcpy(&lg[i], &v, 4);
+            }
+        });
+        if (bad.load() == 1) return fail(VRT_ERR_SCENE, "refraction-index overflow");
+        if (bad.load() == 2) return fail(VRT_ERR_SCENE, "refraction-index underflow");
+    }
+
+    const uint16_t fb[3] = {(uint16_t)(bounds[0] - 2), (uint16_t)(bounds[1] - 2), (uint16_t)(bounds[2] - 2)};
+    const size_t fvox = (size_t)fb[0] * fb[1] * fb[2];
+    const int field_type = ior_type == VRT_F32 ? VRT_F32 : VRT_I16;
+    vrt_engine *e = nullptr;
+    int rc = engine_alloc(&e, fb, field_type, fvox, opt);
+    if (rc) return rc;
     DeviceGuard g(e->device);
-    const vrt_options &o = opt ? *opt : e->opt;
-    const size_t dsz = dir_type == VRT_F32 ? 4 : 2;
+    vrt_scene *sc = new (std::nothrow) vrt_scene();
+    if (!sc) { engine_free(e); return fail(VRT_ERR_OUT_OF_MEMORY, "host allocation failed"); }
+    sc->engine = e;
+    sc->ior_type = ior_type;
+    for (int d = 0; d < 3; ++d) sc->N[d] = (uint32_t)bounds[d];
+    void *d_lg = nullptr, *d_tr = nullptr;
+    auto cleanup = [&](int code) {
+        if (d_lg) (void)hipFree(d_lg);
+        if (d_tr) (void)hipFree(d_tr);
+        vrt_scene_destroy(sc);
+        return code;
+    };
+    rc = engine_init_device(e);
+    if (rc) return cleanup(rc);
+    if (hipMalloc(&d_lg, nvox * 4) != hipSuccess || hipMalloc(&d_tr, nvox * 4) != hipSuccess ||
+        hipMalloc(&sc->d_ior, nvox * 4) != hipSuccess || hipMalloc(&sc->d_err, sizeof(vrt::SceneErr)) != hipSuccess)
+        return cleanup(fail(VRT_ERR_OUT_OF_MEMORY, "device allocation failed"));
     hipStream_t s = e->stream;
-
-    // Rays go up in one piece when no path is requested; with path tracing the device path
-    // buffer (iterations*12 bytes per ray) bounds the chunk, as the reference's 0x8000-ray
-    // chunks bound its own (.cu:798, 840).
-    size_t chunk = nrays;
-    if (path) {
-        const size_t per_ray = (size_t)iterations * 12;
-        const size_t budget = (size_t)2 << 30;
-        chunk = std::max<size_t>(1, std::min(nrays, budget / std::max<size_t>(per_ray, 1)));
-    }
-    HIP_TRY(e->h_in_pos.reserve(chunk * 12));
-    HIP_TRY(e->h_in_dir.reserve(chunk * 3 * dsz));
-    HIP_TRY(e->h_out_pos.reserve(chunk * 12));
-    HIP_TRY(e->h_out_dir.reserve(chunk * 3 * dsz));
-    HIP_TRY(e->h_out_iter.reserve(chunk * 4));
-    HIP_TRY(e->h_out_light.reserve(chunk * 4));
-    if (path) HIP_TRY(e->h_path.reserve(chunk * (size_t)iterations * 12));
-
-    const size_t nchunks = (nrays + chunk - 1) / chunk;
-    bool cap_hit = false;
-    for (size_t c = 0, off = 0; off < nrays; ++c, off += chunk) {
-        const size_t n = std::min(chunk, nrays - off);
-        if (o.loglevel < 0) printf("iteration %zu of %zu\n", c, nchunks);          // .cu:823-826
-        HIP_TRY(hipMemcpyAsync(e->h_in_pos.p, sp + 3 * off, n * 12, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(e->h_in_dir.p, (const char *)sd + 3 * off * dsz, n * 3 * dsz, hipMemcpyHostToDevice, s));
-        rc = trace_device_impl(e, dir_type, n, (const uint32_t *)e->h_in_pos.p, e->h_in_dir.p,
-                               (uint32_t *)e->h_out_pos.p, e->h_out_dir.p, (uint32_t *)e->h_out_iter.p,
-                               (uint32_t *)e->h_out_light.p, path ? (uint32_t *)e->h_path.p : nullptr, invscale,
-                               iterations, s, opt);
-        if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(ep + 3 * off, e->h_out_pos.p, n * 12, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync((char *)ed + 3 * off * dsz, e->h_out_dir.p, n * 3 * dsz, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(ei + off, e->h_out_iter.p, n * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(rl + off, e->h_out_light.p, n * 4, hipMemcpyDeviceToHost, s));
-        if (path)
-            HIP_TRY(hipMemcpyAsync(path + off * (size_t)iterations * 3, e->h_path.p, n * (size_t)iterations * 12,
-                                   hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-    }
-    for (size_t i = 0; i < nrays && !cap_hit; ++i) cap_hit = (ei[i] == iterations);
-    if (cap_hit) printf("Warning, maximum iterations hitted\n");                   // .cu:512-515
-    if (o.loglevel < 0) printf("cpu: 0 gpu: %zu\n", nchunks);                      // .cu:948-951
+    if (hipMemcpyAsync(d_lg, lg.data(), nvox * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(d_tr, translucency, nvox * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(sc->d_ior, ior, nvox * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemsetAsync(sc->d_err, 0, sizeof(vrt::SceneErr), s) != hipSuccess)
+        return cleanup(fail(VRT_ERR_HIP, "scene upload failed"));
+    const unsigned grid = (unsigned)((fvox + 255) / 256);
+    if (ior_type == VRT_F32)
+        vrt::k_scene_build<float, vrt::vox_f32><<<grid, 256, 0, s>>>((const float *)d_lg, (const uint32_t *)d_tr, sc->N[0], sc->N[1],
+                                                                     sc->N[2], (vrt::vox_f32 *)e->field, (vrt::SceneErr *)sc->d_err);
+    else
+        vrt::k_scene_build<int32_t, vrt::vox_i16><<<grid, 256, 0, s>>>((const int32_t *)d_lg, (const uint32_t *)d_tr, sc->N[0], sc->N[1],
+                                                                       sc->N[2], (vrt::vox_i16 *)e->field, (vrt::SceneErr *)sc->d_err);
+    if (hipGetLastError() != hipSuccess) return cleanup(fail(VRT_ERR_HIP, "scene build launch failed"));
+    vrt::SceneErr herr;
+    if (hipMemcpyAsync(&herr, sc->d_err, sizeof herr, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess)
+        return cleanup(fail(VRT_ERR_HIP, "scene build failed: %s", hipGetErrorString(hipGetLastError())));
+    if (herr.diff_overflow) return cleanup(fail(VRT_ERR_SCENE, "differention overflow"));          // image_util.cpp:291-293
+    (void)hipFree(d_lg);
+    (void)hipFree(d_tr);
+    d_lg = d_tr = nullptr;
+    *out = sc;
     return VRT_OK;
 }
+
+int vrt_scene_trace(vrt_scene_handle sc, int dir_type, size_t nrays, const uint32_t *sp, const void *sd, uint32_t *ep,
+                    void *ed, uint32_t *ei, uint32_t *rl, uint32_t *path, const float *invscale,
+                    uint32_t /*min_brightness*/, uint32_t iterations, int /*normalize_length: "|| true", image_util.cpp:668*/,
+                    const vrt_options *opt)
+{
+    if (!sc) return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_scene_trace: NULL scene");
+    vrt_engine *e = sc->engine;
+    int rc = check_trace_args(e, dir_type, nrays, sp, sd, ep, ed, ei, rl, invscale, iterations);
+    if (rc) return rc;
+    if ((sc->ior_type == VRT_F32) != (dir_type == VRT_F32))
+        return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_scene_trace: a %s scene takes %s directions (the reference instantiates "
+                    "only <float,float> and <ior_t,dir_t>, image_util.cpp:940-956)",
+                    sc->ior_type == VRT_F32 ? "float" : "fixed-point", sc->ior_type == VRT_F32 ? "float" : "int16");
+    if (nrays == 0) return VRT_OK;
+    DeviceGuard g(e->device);
+    const size_t dsz = dir_type == VRT_F32 ? 4 : 2;
+    auto pre = [&](uint32_t *d_pos, void *d_dir, size_t n, size_t off, hipStream_t s) -> int {
+        HIP_TRY(sc->pro_pos.reserve(n * 12));
+        HIP_TRY(sc->pro_dir.reserve(n * 3 * dsz));
+        vrt::SceneErr init = {0u, 0xFFFFFFFFu, 0u};
+        HIP_TRY(hipMemcpyAsync(sc->d_err, &init, sizeof init, hipMemcpyHostToDevice, s));
+        const unsigned grid = (unsigned)((n + 255) / 256);
+        if (dir_type == VRT_F32)
+            vrt::k_ray_prologue<float, float><<<grid, 256, 0, s>>>((const float *)sc->d_ior, sc->N[0], sc->N[1], sc->N[2], d_pos,
+                                                                   (const float *)d_dir, (uint32_t *)sc->pro_pos.p,
+                                                                   (float *)sc->pro_dir.p, (uint32_t)n, (vrt::SceneErr *)sc->d_err);
+        else
+            vrt::k_ray_prologue<uint32_t, int16_t><<<grid, 256, 0, s>>>((const uint32_t *)sc->d_ior, sc->N[0], sc->N[1], sc->N[2], d_pos,
+                                                                        (const int16_t *)d_dir, (uint32_t *)sc->pro_pos.p,
+                                                                        (int16_t *)sc->pro_dir.p, (uint32_t)n, (vrt::SceneErr *)sc->d_err);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(d_pos, sc->pro_pos.p, n * 12, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_dir, sc->pro_dir.p, n * 3 * dsz, hipMemcpyDeviceToDevice, s));
+        vrt::SceneErr herr;
+        HIP_TRY(hipMemcpyAsync(&herr, sc->d_err, sizeof herr, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (herr.first_bad_ray != 0xFFFFFFFFu) {                                   // image_util.cpp:690-695
+            const size_t i = off + herr.first_bad_ray;
+            return fail(VRT_ERR_RAY_RANGE, "ray %zu:%g %g %g is not in 0 to %u %u %u", i, sp[3 * i] / 65536.0,
+                        sp[3 * i + 1] / 65536.0, sp[3 * i + 2] / 65536.0, sc->N[0], sc->N[1], sc->N[2]);
+        }
+        if (herr.normalize_overflow)                                               // image_util.cpp:705-708
+            return fail(VRT_ERR_SCENE, "Normalize length failed: -32768<=tmp<=32767");
+        return VRT_OK;
+    };
+    return trace_host_impl(e, dir_type, nrays, sp, sd, ep, ed, ei, rl, path, invscale, iterations, opt, 0x10000u, pre);
+}
+
+void vrt_scene_destroy(vrt_scene_handle sc)
+{
+    if (!sc) return;
+    if (sc->engine) {
+        DeviceGuard g(sc->engine->device);
+        if (sc->d_ior) (void)hipFree(sc->d_ior);
+        if (sc->d_err) (void)hipFree(sc->d_err);
+        sc->pro_pos.release();
+        sc->pro_dir.release();
+        engine_free(sc->engine);
+    }
+    delete sc;
+}
+
+vrt_handle vrt_scene_engine(vrt_scene_handle sc) { return sc ? sc->engine : nullptr; }
 
 void vrt_destroy(vrt_handle h) { engine_free(h); }
 

@@ -34,6 +34,8 @@ struct MarchParams {
     uint32_t nrays;
     uint32_t slab_lds_bytes;  // slab kernel: LDS bytes per wave
     unsigned long long *stats; // optional debug counters (nullptr in production), see vrt_slab.h
+    uint32_t out_pos_bias;    // added to end_pos / path on output: 0 at the seam, 0x10000 for the scene
+                              // layer's "+0x10000" epilogue (image_util.cpp:770-771)
 };
 
 struct f4 { float x, y, z, w; };
@@ -150,7 +152,7 @@ template <typename DirT>
 __device__ __forceinline__ void store_ray(const MarchParams &p, uint32_t ray, const Ray &r, uint32_t remaining)
 {
     uint32_t *ep = p.end_pos + 3 * (size_t)ray;
-    ep[0] = r.px; ep[1] = r.py; ep[2] = r.pz;
+    ep[0] = r.px + p.out_pos_bias; ep[1] = r.py + p.out_pos_bias; ep[2] = r.pz + p.out_pos_bias;
     DirT *ed = (DirT *)p.end_dir + 3 * (size_t)ray;
     if constexpr (sizeof(DirT) == 4) {
         ed[0] = r.dx * (1.0f / 65536.0f); ed[1] = r.dy * (1.0f / 65536.0f); ed[2] = r.dz * (1.0f / 65536.0f);
@@ -163,10 +165,10 @@ __device__ __forceinline__ void store_ray(const MarchParams &p, uint32_t ray, co
     p.remaining_light[ray] = 0xFFFFFFFFu;
 }
 
-__device__ __forceinline__ void path_put(uint32_t *pb, uint32_t it, const Ray &r)
+__device__ __forceinline__ void path_put(uint32_t *pb, uint32_t it, const Ray &r, uint32_t bias)
 {
     uint32_t *q = pb + 3 * (size_t)it;
-    q[0] = r.px; q[1] = r.py; q[2] = r.pz;
+    q[0] = r.px + bias; q[1] = r.py + bias; q[2] = r.pz + bias;
 }
 
 // =========================================================================================
@@ -204,16 +206,16 @@ __global__ __launch_bounds__(256) void k_march_direct(const MarchParams p)
     uint32_t *pb = PATH ? p.path + (size_t)p.iterations * 3 * ray : nullptr;
 
     uint32_t it = p.iterations - 1;                     // .cu:333
-    if (PATH) path_put(pb, it, r);
+    if (PATH) path_put(pb, it, r, p.out_pos_bias);
     while (it-- > 0 && in_field(r, bx1, by1, bz1)) {    // .cu:335
         f4 c[8];
         gather_global<FieldT>(f, r, p.By, p.Bz, c);
         if (march_step(r, c, p.invx, p.invy, p.invz)) break;
-        if (PATH) path_put(pb, it, r);
+        if (PATH) path_put(pb, it, r, p.out_pos_bias);
     }
     ++it;                                               // .cu:350
     const uint32_t remaining = it;
-    if (PATH) { while (it-- > 0) path_put(pb, it, r); } // .cu:352-358
+    if (PATH) { while (it-- > 0) path_put(pb, it, r, p.out_pos_bias); } // .cu:352-358
     store_ray<DirT>(p, ray, r, remaining);
 }
 
