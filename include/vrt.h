@@ -171,6 +171,20 @@ int vrt_scene_create(vrt_scene_handle *out, int dim, const size_t *bounds, int i
                      const uint32_t *translucency, size_t nvox, const vrt_options *opt);
 
 /*
+ * BASELINE config 5 (SURVEY §0 reading A, row f-3): an 8-bit density volume with a 256-entry transfer
+ * function d -> (ior, translucency).  The reference has no 8-bit path; this call is defined as
+ * vrt_scene_create on the expanded arrays ior[i] = lut_ior[density[i]], translucency[i] =
+ * lut_translucency[density[i]] (so the reference on the expanded arrays is the oracle), but only the
+ * 1-byte volume is uploaded and kept: the logarithm is taken of the 256 table entries and the stencil
+ * and the ray front end read the volume through the table.
+ *   density          HOST pointer, nvox bytes
+ *   lut_ior          256 entries, float (VRT_F32) or ior_t 16.16 (VRT_U32)
+ *   lut_translucency 256 entries
+ */
+int vrt_scene_create_lut(vrt_scene_handle *out, int dim, const size_t *bounds, int ior_type, const uint8_t *density,
+                         const void *lut_ior, const uint32_t *lut_translucency, size_t nvox, const vrt_options *opt);
+
+/*
  * Replaces RaytraceScene::trace_rays<DirType>(...) (image_util.cpp:645-772): range check
  * (VRT_ERR_RAY_RANGE, "ray i:... is not in 0 to ..."), -0x8000 shift, ior interpolation, direction
  * normalisation (always on, as the reference's "normalize_length || true"), second shift, the march,

@@ -16,6 +16,9 @@ Fixtures:
   F4_caps                iteration caps 1, 2, 3, 17 on the F2 rays: pins end_iteration/remaining.
   L4_scene_{f32,i16}     20^3 ior volume through RaytraceScene (scene build + ray front end + trace),
                          with the reference's derivative arrays for the scene-build check.
+  F5_lut_{f32,i16}       BASELINE config 5 semantics (SURVEY §0 reading A) at 32^3: uint8 density + 256-entry
+                         (ior, translucency) transfer function, expanded on the host and fed to the
+                         reference; opaque cores terminate rays through the live w>0 test.
   F6_config1             BASELINE config 1 (64^3, 256x256 orthographic, int16 family via the
                          python_binding.cpp instantiation): SHA-256 of the outputs + summary stats.
 """
@@ -60,9 +63,36 @@ def scaling_inputs(dt_ior, dt_dir):
     return b, ior, tr, sp, sd
 
 
+def lut_fixture(ref):
+    N = 32
+    dens, lut_ior_f, lut_tr = W.uint8_density_and_lut(N)
+    dens = dens.reshape(-1)
+    rng = np.random.RandomState(31)
+    pv = 1.0 + rng.rand(640, 3) * (N - 2.001)
+    sp = np.round(pv * 65536).astype(np.uint32).reshape(-1)
+    d = rng.randn(640, 3)
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    for tag in ("f32", "i16"):
+        if tag == "f32":
+            lut_ior = lut_ior_f
+            sd = d.astype(np.float32).reshape(-1)
+        else:
+            lut_ior = np.round(lut_ior_f.astype(np.float64) * 65536).astype(np.uint32)
+            sd = np.round(d * 256).astype(np.int16).reshape(-1)
+        ior = lut_ior[dens]                     # the expansion the reference needs
+        tr = lut_tr[dens]
+        r = ref.scene_trace([N] * 3, ior, tr, sp, sd, [1, 1, 1], 100000, False)
+        save("F5_lut_" + tag, bounds=np.array([N] * 3), density=dens, lut_ior=lut_ior, lut_translucency=lut_tr,
+             start_position=sp, start_direction=sd, invscale=np.float32([1, 1, 1]), iterations=np.uint32(100000),
+             **{k: r[k] for k in KEYS})
+
+
 def main():
     assert oracle.ref.available(), "build the reference first: make -C oracle ref"
     ref = oracle.ref
+    lut_fixture(ref)
+    if "--only-lut" in sys.argv:
+        return
 
     # ---- F1
     for tag, dti, dtd in (("f32", np.float32, np.float32), ("i16", np.uint32, np.int16)):

@@ -100,3 +100,21 @@ def test_scene_errors():
         assert e.value.code == -7 and "ray 1:" in str(e.value) and "is not in 0 to" in str(e.value)
         with pytest.raises(capi.VrtError):                   # float scene takes float directions only
             sc.trace_rays(sp[:3], np.array([256, 0, 0], np.int16), [1, 1, 1], 10)
+
+
+@pytest.mark.parametrize("tag", ["f32", "i16"])
+def test_lut_scene_golden(golden_dir, tag):
+    """BASELINE config 5 semantics (row f-3): uint8 density + 256-entry transfer function, expanded on
+    the device; the golden outputs come from the reference on the host-expanded arrays."""
+    g = np.load(os.path.join(golden_dir, "F5_lut_%s.npz" % tag))
+    with capi.Scene.from_lut(g["bounds"], g["density"], g["lut_ior"], g["lut_translucency"]) as sc:
+        out = sc.trace_rays(g["start_position"], g["start_direction"], g["invscale"], int(g["iterations"]))
+    for k in KEYS:
+        assert _same(out[k], g[k]), k
+    # and the expanded-array scene gives the same bits as the LUT scene
+    ior = g["lut_ior"][g["density"]]
+    tr = g["lut_translucency"][g["density"]]
+    with capi.Scene(g["bounds"], ior, tr) as sc2:
+        out2 = sc2.trace_rays(g["start_position"], g["start_direction"], g["invscale"], int(g["iterations"]))
+    for k in KEYS:
+        assert _same(out2[k], g[k]), k

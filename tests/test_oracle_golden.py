@@ -137,3 +137,16 @@ def test_w_channel_extremes():
     zi = np.zeros(tr.size, np.int16)
     fi = oracle.port.interleave(zi, zi, zi, tr)[:, 3]
     assert fi.tolist() == [32767, 32767, 0, 0, -1, -1, -32768]
+
+
+@pytest.mark.parametrize("tag", ["f32", "i16"])
+def test_lut_expansion_golden(golden_dir, tag):
+    """Config 5 semantics: the oracle on the host-expanded (ior, translucency) arrays."""
+    g = _load(golden_dir, "F5_lut_" + tag)
+    ior = g["lut_ior"][g["density"]]
+    tr = g["lut_translucency"][g["density"]]
+    out = oracle.port.scene_trace(g["bounds"], ior, tr, g["start_position"], g["start_direction"], g["invscale"],
+                                  int(g["iterations"]))
+    for k in KEYS:
+        assert _same(out[k], g[k]), k
+    assert (out["end_iteration"] < 20).sum() > 10      # opaque cores stop rays early (w > 0)

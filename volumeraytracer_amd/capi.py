@@ -19,7 +19,7 @@ ABI_SYMBOLS = (
     "vrt_options_default", "vrt_device_count", "vrt_abi_version", "vrt_create", "vrt_create_from_device",
     "vrt_trace", "vrt_trace_device", "vrt_destroy", "vrt_engine_device", "vrt_engine_field_bytes",
     "vrt_engine_field_device_ptr", "vrt_engine_last_march_ms", "vrt_engine_debug_stats",
-    "vrt_last_error", "vrt_scene_create", "vrt_scene_trace", "vrt_scene_destroy", "vrt_scene_engine",
+    "vrt_last_error", "vrt_scene_create", "vrt_scene_create_lut", "vrt_scene_trace", "vrt_scene_destroy", "vrt_scene_engine",
 )
 
 
@@ -89,6 +89,8 @@ def load():
     if hasattr(L, "vrt_scene_create"):
         L.vrt_scene_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_size_t), C.c_int, vp, u32p, sz,
                                        C.POINTER(Options)]
+        L.vrt_scene_create_lut.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_size_t), C.c_int, vp, vp, u32p, sz,
+                                           C.POINTER(Options)]
         L.vrt_scene_trace.argtypes = [vp, C.c_int, sz, u32p, vp, u32p, vp, u32p, u32p, u32p, vp, C.c_uint32,
                                       C.c_uint32, C.c_int, C.POINTER(Options)]
         L.vrt_scene_destroy.argtypes = [vp]
@@ -262,6 +264,34 @@ class Scene:
                                  C.byref(options) if options is not None else None))
         self._h = h
         self.bounds = [int(x) for x in bounds]
+
+    @classmethod
+    def from_lut(cls, bounds, density, lut_ior, lut_translucency, options=None):
+        """vrt_scene_create_lut: uint8 density volume + 256-entry (ior, translucency) transfer function."""
+        L = load()
+        self = cls.__new__(cls)
+        dens = np.ascontiguousarray(density, dtype=np.uint8).reshape(-1)
+        lut_ior = np.ascontiguousarray(lut_ior).reshape(-1)
+        if lut_ior.dtype == np.float32:
+            self.ior_type = VRT_F32
+        else:
+            lut_ior = np.ascontiguousarray(lut_ior, dtype=np.uint32)
+            self.ior_type = VRT_U32
+        lut_tr = np.ascontiguousarray(lut_translucency, dtype=np.uint32).reshape(-1)
+        if lut_ior.size != 256 or lut_tr.size != 256:
+            raise VrtError(-1, "transfer function tables need 256 entries")
+        b = (C.c_size_t * len(bounds))(*[int(x) for x in bounds])
+        h = C.c_void_p()
+        check(L.vrt_scene_create_lut(C.byref(h), len(bounds), b, self.ior_type, _np_ptr(dens), _np_ptr(lut_ior),
+                                     _np_ptr(lut_tr), dens.size, C.byref(options) if options is not None else None))
+        self._h = h
+        self.bounds = [int(x) for x in bounds]
+        return self
+
+    @property
+    def engine_handle(self):
+        """The seam-level vrt_handle inside the scene (owned by the scene)."""
+        return C.c_void_p(load().vrt_scene_engine(self._h))
 
     def trace_rays(self, start_position, start_direction, invscale, iterations, trace_paths=False,
                    minimum_brightness=0, normalize_length=True, options=None):

@@ -386,6 +386,8 @@ struct vrt_scene {
     int ior_type = VRT_F32;
     uint32_t N[3] = {0, 0, 0};
     void *d_ior = nullptr;          // the ior volume stays resident for the ray prologue's interpolation
+    void *d_density = nullptr;      // LUT scenes: the 8-bit volume stays resident instead, with its ior table
+    void *d_lut_ior = nullptr;
     void *d_err = nullptr;          // vrt::SceneErr
     DevBuf pro_pos, pro_dir;
 };
@@ -502,8 +504,10 @@ int vrt_trace(vrt_handle h, int dir_type, size_t nrays, const uint32_t *sp, cons
 
 // ---- scene layer ---------------------------------------------------------------------------
 
-int vrt_scene_create(vrt_scene_handle *out, int dim, const size_t *bounds, int ior_type, const void *ior,
-                     const uint32_t *translucency, size_t nvox, const vrt_options *opt)
+// Shared by vrt_scene_create (density == nullptr: `ior`/`translucency` are nvox-element arrays) and
+// vrt_scene_create_lut (density != nullptr: they are 256-entry tables indexed by the 8-bit volume).
+static int scene_create_impl(vrt_scene_handle *out, int dim, const size_t *bounds, int ior_type, const uint8_t *density,
+                             const void *ior, const uint32_t *translucency, size_t nvox, const vrt_options *opt)
 {
     if (!out) return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_scene_create: out is NULL");
     *out = nullptr;
@@ -519,12 +523,14 @@ int vrt_scene_create(vrt_scene_handle *out, int dim, const size_t *bounds, int i
         if (bounds[d] < 3 || bounds[d] > 65535)
             return fail(VRT_ERR_SCENE, "bounds[%d] = %zu: the 3x3x3 stencil needs 3 <= extent <= 65535", d, bounds[d]);
 
-    // ior_log on the host with the libm the reference itself calls (image_util.cpp:531-543, 605-611)
-    std::vector<uint32_t> lg(nvox);                     // float or int32 bit patterns
+    // ior_log on the host with the libm the reference itself calls (image_util.cpp:531-543, 605-611);
+    // for a LUT scene only the 256 table entries need a logarithm.
+    const size_t nlog = density ? 256 : nvox;
+    std::vector<uint32_t> lg(nlog);                     // float or int32 bit patterns
     std::atomic<int> bad{0};
     if (ior_type == VRT_F32) {
         const float *f = (const float *)ior;
-        host_parallel_for(nvox, [&](size_t b, size_t e2) {
+        host_parallel_for(nlog, [&](size_t b, size_t e2) {
             for (size_t i = b; i < e2; ++i) {
                 if (f[i] <= 0) { bad.store(1); continue; }
                 const float v = (float)(std::log((double)f[i]) * (double)0x420000);
@@ -534,7 +540,7 @@ int vrt_scene_create(vrt_scene_handle *out, int dim, const size_t *bounds, int i
         if (bad.load()) return fail(VRT_ERR_SCENE, "refraction-index underflow: ior <= 0");
     } else {
         const uint32_t *u = (const uint32_t *)ior;
-        host_parallel_for(nvox, [&](size_t b, size_t e2) {
+        host_parallel_for(nlog, [&](size_t b, size_t e2) {
             for (size_t i = b; i < e2; ++i) {
                 const double tmp = std::log((double)u[i] / 65536.0) * (double)0x420000;
                 if (tmp > 2147483647.0) { bad.store(1); continue; }
@@ -568,22 +574,44 @@ int vrt_scene_create(vrt_scene_handle *out, int dim, const size_t *bounds, int i
     };
     rc = engine_init_device(e);
     if (rc) return cleanup(rc);
-    if (hipMalloc(&d_lg, nvox * 4) != hipSuccess || hipMalloc(&d_tr, nvox * 4) != hipSuccess ||
-        hipMalloc(&sc->d_ior, nvox * 4) != hipSuccess || hipMalloc(&sc->d_err, sizeof(vrt::SceneErr)) != hipSuccess)
-        return cleanup(fail(VRT_ERR_OUT_OF_MEMORY, "device allocation failed"));
     hipStream_t s = e->stream;
-    if (hipMemcpyAsync(d_lg, lg.data(), nvox * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
-        hipMemcpyAsync(d_tr, translucency, nvox * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
-        hipMemcpyAsync(sc->d_ior, ior, nvox * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
+    const size_t ntab = density ? 256 : nvox;
+    if (hipMalloc(&d_lg, ntab * 4) != hipSuccess || hipMalloc(&d_tr, ntab * 4) != hipSuccess ||
+        hipMalloc(&sc->d_err, sizeof(vrt::SceneErr)) != hipSuccess)
+        return cleanup(fail(VRT_ERR_OUT_OF_MEMORY, "device allocation failed"));
+    if (density) {
+        if (hipMalloc(&sc->d_density, nvox) != hipSuccess || hipMalloc(&sc->d_lut_ior, 256 * 4) != hipSuccess)
+            return cleanup(fail(VRT_ERR_OUT_OF_MEMORY, "device allocation failed"));
+        if (hipMemcpyAsync(sc->d_density, density, nvox, hipMemcpyHostToDevice, s) != hipSuccess ||
+            hipMemcpyAsync(sc->d_lut_ior, ior, 256 * 4, hipMemcpyHostToDevice, s) != hipSuccess)
+            return cleanup(fail(VRT_ERR_HIP, "scene upload failed"));
+    } else {
+        if (hipMalloc(&sc->d_ior, nvox * 4) != hipSuccess) return cleanup(fail(VRT_ERR_OUT_OF_MEMORY, "device allocation failed"));
+        if (hipMemcpyAsync(sc->d_ior, ior, nvox * 4, hipMemcpyHostToDevice, s) != hipSuccess)
+            return cleanup(fail(VRT_ERR_HIP, "scene upload failed"));
+    }
+    if (hipMemcpyAsync(d_lg, lg.data(), ntab * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(d_tr, translucency, ntab * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
         hipMemsetAsync(sc->d_err, 0, sizeof(vrt::SceneErr), s) != hipSuccess)
         return cleanup(fail(VRT_ERR_HIP, "scene upload failed"));
     const unsigned grid = (unsigned)((fvox + 255) / 256);
-    if (ior_type == VRT_F32)
-        vrt::k_scene_build<float, vrt::vox_f32><<<grid, 256, 0, s>>>((const float *)d_lg, (const uint32_t *)d_tr, sc->N[0], sc->N[1],
-                                                                     sc->N[2], (vrt::vox_f32 *)e->field, (vrt::SceneErr *)sc->d_err);
-    else
-        vrt::k_scene_build<int32_t, vrt::vox_i16><<<grid, 256, 0, s>>>((const int32_t *)d_lg, (const uint32_t *)d_tr, sc->N[0], sc->N[1],
-                                                                       sc->N[2], (vrt::vox_i16 *)e->field, (vrt::SceneErr *)sc->d_err);
+    vrt::SceneErr *derr = (vrt::SceneErr *)sc->d_err;
+    const uint8_t *dd = (const uint8_t *)sc->d_density;
+    if (ior_type == VRT_F32) {
+        if (density)
+            vrt::k_scene_build<<<grid, 256, 0, s>>>(vrt::SrcLut<float>{dd, (const float *)d_lg}, vrt::SrcLut<uint32_t>{dd, (const uint32_t *)d_tr},
+                                                    sc->N[0], sc->N[1], sc->N[2], (vrt::vox_f32 *)e->field, derr);
+        else
+            vrt::k_scene_build<<<grid, 256, 0, s>>>(vrt::SrcArray<float>{(const float *)d_lg}, vrt::SrcArray<uint32_t>{(const uint32_t *)d_tr},
+                                                    sc->N[0], sc->N[1], sc->N[2], (vrt::vox_f32 *)e->field, derr);
+    } else {
+        if (density)
+            vrt::k_scene_build<<<grid, 256, 0, s>>>(vrt::SrcLut<int32_t>{dd, (const int32_t *)d_lg}, vrt::SrcLut<uint32_t>{dd, (const uint32_t *)d_tr},
+                                                    sc->N[0], sc->N[1], sc->N[2], (vrt::vox_i16 *)e->field, derr);
+        else
+            vrt::k_scene_build<<<grid, 256, 0, s>>>(vrt::SrcArray<int32_t>{(const int32_t *)d_lg}, vrt::SrcArray<uint32_t>{(const uint32_t *)d_tr},
+                                                    sc->N[0], sc->N[1], sc->N[2], (vrt::vox_i16 *)e->field, derr);
+    }
     if (hipGetLastError() != hipSuccess) return cleanup(fail(VRT_ERR_HIP, "scene build launch failed"));
     vrt::SceneErr herr;
     if (hipMemcpyAsync(&herr, sc->d_err, sizeof herr, hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -595,6 +623,19 @@ int vrt_scene_create(vrt_scene_handle *out, int dim, const size_t *bounds, int i
     d_lg = d_tr = nullptr;
     *out = sc;
     return VRT_OK;
+}
+
+int vrt_scene_create(vrt_scene_handle *out, int dim, const size_t *bounds, int ior_type, const void *ior,
+                     const uint32_t *translucency, size_t nvox, const vrt_options *opt)
+{
+    return scene_create_impl(out, dim, bounds, ior_type, nullptr, ior, translucency, nvox, opt);
+}
+
+int vrt_scene_create_lut(vrt_scene_handle *out, int dim, const size_t *bounds, int ior_type, const uint8_t *density,
+                         const void *lut_ior, const uint32_t *lut_translucency, size_t nvox, const vrt_options *opt)
+{
+    if (!density) return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_scene_create_lut: density is NULL");
+    return scene_create_impl(out, dim, bounds, ior_type, density, lut_ior, lut_translucency, nvox, opt);
 }
 
 int vrt_scene_trace(vrt_scene_handle sc, int dir_type, size_t nrays, const uint32_t *sp, const void *sd, uint32_t *ep,
@@ -619,14 +660,19 @@ int vrt_scene_trace(vrt_scene_handle sc, int dir_type, size_t nrays, const uint3
         vrt::SceneErr init = {0u, 0xFFFFFFFFu, 0u};
         HIP_TRY(hipMemcpyAsync(sc->d_err, &init, sizeof init, hipMemcpyHostToDevice, s));
         const unsigned grid = (unsigned)((n + 255) / 256);
-        if (dir_type == VRT_F32)
-            vrt::k_ray_prologue<float, float><<<grid, 256, 0, s>>>((const float *)sc->d_ior, sc->N[0], sc->N[1], sc->N[2], d_pos,
-                                                                   (const float *)d_dir, (uint32_t *)sc->pro_pos.p,
-                                                                   (float *)sc->pro_dir.p, (uint32_t)n, (vrt::SceneErr *)sc->d_err);
-        else
-            vrt::k_ray_prologue<uint32_t, int16_t><<<grid, 256, 0, s>>>((const uint32_t *)sc->d_ior, sc->N[0], sc->N[1], sc->N[2], d_pos,
-                                                                        (const int16_t *)d_dir, (uint32_t *)sc->pro_pos.p,
-                                                                        (int16_t *)sc->pro_dir.p, (uint32_t)n, (vrt::SceneErr *)sc->d_err);
+        vrt::SceneErr *derr = (vrt::SceneErr *)sc->d_err;
+        const uint8_t *dd = (const uint8_t *)sc->d_density;
+        if (dir_type == VRT_F32) {
+            if (dd) vrt::k_ray_prologue<<<grid, 256, 0, s>>>(vrt::SrcLut<float>{dd, (const float *)sc->d_lut_ior}, sc->N[0], sc->N[1], sc->N[2], d_pos,
+                                                             (const float *)d_dir, (uint32_t *)sc->pro_pos.p, (float *)sc->pro_dir.p, (uint32_t)n, derr);
+            else    vrt::k_ray_prologue<<<grid, 256, 0, s>>>(vrt::SrcArray<float>{(const float *)sc->d_ior}, sc->N[0], sc->N[1], sc->N[2], d_pos,
+                                                             (const float *)d_dir, (uint32_t *)sc->pro_pos.p, (float *)sc->pro_dir.p, (uint32_t)n, derr);
+        } else {
+            if (dd) vrt::k_ray_prologue<<<grid, 256, 0, s>>>(vrt::SrcLut<uint32_t>{dd, (const uint32_t *)sc->d_lut_ior}, sc->N[0], sc->N[1], sc->N[2], d_pos,
+                                                             (const int16_t *)d_dir, (uint32_t *)sc->pro_pos.p, (int16_t *)sc->pro_dir.p, (uint32_t)n, derr);
+            else    vrt::k_ray_prologue<<<grid, 256, 0, s>>>(vrt::SrcArray<uint32_t>{(const uint32_t *)sc->d_ior}, sc->N[0], sc->N[1], sc->N[2], d_pos,
+                                                             (const int16_t *)d_dir, (uint32_t *)sc->pro_pos.p, (int16_t *)sc->pro_dir.p, (uint32_t)n, derr);
+        }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(d_pos, sc->pro_pos.p, n * 12, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(d_dir, sc->pro_dir.p, n * 3 * dsz, hipMemcpyDeviceToDevice, s));
@@ -651,6 +697,8 @@ void vrt_scene_destroy(vrt_scene_handle sc)
     if (sc->engine) {
         DeviceGuard g(sc->engine->device);
         if (sc->d_ior) (void)hipFree(sc->d_ior);
+        if (sc->d_density) (void)hipFree(sc->d_density);
+        if (sc->d_lut_ior) (void)hipFree(sc->d_lut_ior);
         if (sc->d_err) (void)hipFree(sc->d_err);
         sc->pro_pos.release();
         sc->pro_dir.release();

@@ -26,6 +26,19 @@ __device__ __forceinline__ int stamp_m(int a, int b)
     return ca && cb ? 162 : (ca || cb ? 47 : 14);
 }
 
+// Voxel sources: a plain array, or an 8-bit density volume seen through a 256-entry table
+// (BASELINE config 5 / SURVEY row f-3, reading A: the table is expanded on the fly, so the stencil and
+// the ior interpolation see exactly the arrays the reference would be given).
+template <typename T> struct SrcArray {
+    const T *a;
+    __device__ __forceinline__ T operator()(size_t i) const { return a[i]; }
+};
+template <typename T> struct SrcLut {
+    const uint8_t *d;
+    const T *lut;
+    __device__ __forceinline__ T operator()(size_t i) const { return lut[d[i]]; }
+};
+
 struct SceneErr {            // device -> host error words
     unsigned int diff_overflow;       // "differention overflow" (image_util.cpp:291-293)
     unsigned int first_bad_ray;       // 0xFFFFFFFF = none; else lowest ray index failing the range check
@@ -34,8 +47,8 @@ struct SceneErr {            // device -> host error words
 
 // One thread per output voxel; terms are accumulated in the reference's order: ascending linear
 // stamp index (i major, k minor) with zero coefficients skipped (image_util.cpp:401-411).
-template <typename LogT, typename VoxT>
-__global__ __launch_bounds__(256) void k_scene_build(const LogT *__restrict__ lg, const uint32_t *__restrict__ transl,
+template <typename LogSrc, typename TrSrc, typename VoxT>
+__global__ __launch_bounds__(256) void k_scene_build(const LogSrc lg, const TrSrc transl,
                                                      uint32_t Nx, uint32_t Ny, uint32_t Nz, VoxT *__restrict__ field,
                                                      SceneErr *err)
 {
@@ -46,7 +59,7 @@ __global__ __launch_bounds__(256) void k_scene_build(const LogT *__restrict__ lg
     const uint32_t z = (uint32_t)(idx % Oz);
     const size_t t = idx / Oz;
     const uint32_t y = (uint32_t)(t % Oy), x = (uint32_t)(t / Oy);
-    const LogT *p = lg + ((size_t)x * Ny + y) * Nz + z;
+    const size_t p0 = ((size_t)x * Ny + y) * Nz + z;
     const size_t sy = Nz, sx = (size_t)Ny * Nz;
 
     if constexpr (sizeof(VoxT) == 16) {                   // float family: RaytraceScene<float,float,float>
@@ -57,13 +70,13 @@ __global__ __launch_bounds__(256) void k_scene_build(const LogT *__restrict__ lg
             for (int j = 0; j < 3; ++j)
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const float v = (float)p[i * sx + j * sy + k];
+                    const float v = (float)lg(p0 + i * sx + j * sy + k);
                     if (i != 1) sum[0] = fma_((float)((i - 1) * stamp_m(j, k)), v, sum[0]);
                     if (j != 1) sum[1] = fma_((float)((j - 1) * stamp_m(i, k)), v, sum[1]);
                     if (k != 1) sum[2] = fma_((float)((k - 1) * stamp_m(i, j)), v, sum[2]);
                 }
         const float weight = 812.0f * 256.0f;
-        const uint32_t tr = transl[((size_t)(x + 1) * Ny + (y + 1)) * Nz + (z + 1)];      // crop_matrix, :300-319
+        const uint32_t tr = transl(((size_t)(x + 1) * Ny + (y + 1)) * Nz + (z + 1));      // crop_matrix, :300-319
         VoxT o;
         o.x = sum[0] / weight; o.y = sum[1] / weight; o.z = sum[2] / weight;              // "sum /= weight", :283-285
         o.w = (float)((int32_t)(0x7FFFFFFFu - tr) / 0x10000);                             // cuda_volume_raytracer.cu:656-659
@@ -76,7 +89,7 @@ __global__ __launch_bounds__(256) void k_scene_build(const LogT *__restrict__ lg
             for (int j = 0; j < 3; ++j)
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const uint32_t v = (uint32_t)p[i * sx + j * sy + k];
+                    const uint32_t v = (uint32_t)lg(p0 + i * sx + j * sy + k);
                     if (i != 1) sum[0] += (uint32_t)((i - 1) * stamp_m(j, k)) * v;
                     if (j != 1) sum[1] += (uint32_t)((j - 1) * stamp_m(i, k)) * v;
                     if (k != 1) sum[2] += (uint32_t)((k - 1) * stamp_m(i, j)) * v;
@@ -92,7 +105,7 @@ __global__ __launch_bounds__(256) void k_scene_build(const LogT *__restrict__ lg
             ovf |= (int32_t)o[a] != q;
         }
         if (ovf) atomicOr(&err->diff_overflow, 1u);
-        const uint32_t tr = transl[((size_t)(x + 1) * Ny + (y + 1)) * Nz + (z + 1)];
+        const uint32_t tr = transl(((size_t)(x + 1) * Ny + (y + 1)) * Nz + (z + 1));
         VoxT v;
         v.x = o[0]; v.y = o[1]; v.z = o[2];
         v.w = (int16_t)((int32_t)(0x7FFFFFFFu - tr) / 0x10000);
@@ -103,13 +116,14 @@ __global__ __launch_bounds__(256) void k_scene_build(const LogT *__restrict__ lg
 // ---- ray prologue (image_util.cpp:673-722) ---------------------------------------------------
 
 // interpolator<float>::operator() (image_util.h:390-431)
-__device__ __forceinline__ float interp_ior(const float *ior, uint32_t Ny, uint32_t Nz, const uint32_t p[3])
+template <typename Src>
+__device__ __forceinline__ float interp_ior_f(const Src ior, uint32_t Ny, uint32_t Nz, const uint32_t p[3])
 {
     const size_t base = ((size_t)(p[0] >> 16) * Ny + (p[1] >> 16)) * Nz + (p[2] >> 16);
     const size_t o2 = Nz, o4 = (size_t)Ny * Nz;
     float v[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = ior[base + ((k & 1) ? 1 : 0) + ((k & 2) ? o2 : 0) + ((k & 4) ? o4 : 0)];
+    for (int k = 0; k < 8; ++k) v[k] = ior(base + ((k & 1) ? 1 : 0) + ((k & 2) ? o2 : 0) + ((k & 4) ? o4 : 0));
     int cnt = 8;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -124,13 +138,14 @@ __device__ __forceinline__ float interp_ior(const float *ior, uint32_t Ny, uint3
 }
 
 // interpolator<ior_t>::operator() (image_util.h:348-388)
-__device__ __forceinline__ uint32_t interp_ior(const uint32_t *ior, uint32_t Ny, uint32_t Nz, const uint32_t p[3])
+template <typename Src>
+__device__ __forceinline__ uint32_t interp_ior_u(const Src ior, uint32_t Ny, uint32_t Nz, const uint32_t p[3])
 {
     const size_t base = ((size_t)(p[0] >> 16) * Ny + (p[1] >> 16)) * Nz + (p[2] >> 16);
     const size_t o2 = Nz, o4 = (size_t)Ny * Nz;
     uint32_t v[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = ior[base + ((k & 1) ? 1 : 0) + ((k & 2) ? o2 : 0) + ((k & 4) ? o4 : 0)];
+    for (int k = 0; k < 8; ++k) v[k] = ior(base + ((k & 1) ? 1 : 0) + ((k & 2) ? o2 : 0) + ((k & 4) ? o4 : 0));
     int cnt = 8;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -143,8 +158,8 @@ __device__ __forceinline__ uint32_t interp_ior(const uint32_t *ior, uint32_t Ny,
     return v[0];
 }
 
-template <typename IorT, typename DirT>
-__global__ __launch_bounds__(256) void k_ray_prologue(const IorT *__restrict__ ior, uint32_t Nx, uint32_t Ny, uint32_t Nz,
+template <typename IorSrc, typename DirT>
+__global__ __launch_bounds__(256) void k_ray_prologue(const IorSrc ior, uint32_t Nx, uint32_t Ny, uint32_t Nz,
                                                       const uint32_t *__restrict__ pos_in, const DirT *__restrict__ dir_in,
                                                       uint32_t *__restrict__ pos_out, DirT *__restrict__ dir_out,
                                                       uint32_t n, SceneErr *err)
@@ -165,13 +180,15 @@ __global__ __launch_bounds__(256) void k_ray_prologue(const IorT *__restrict__ i
     }
 #pragma unroll
     for (int d = 0; d < 3; ++d) p[d] -= 0x8000u;
-    const IorT s = interp_ior(ior, Ny, Nz, p);
+    float sf = 0.0f;
+    uint32_t su = 0u;
+    if constexpr (sizeof(DirT) == 4) sf = interp_ior_f(ior, Ny, Nz, p); else su = interp_ior_u(ior, Ny, Nz, p);
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         if constexpr (sizeof(DirT) == 4) {
-            dir_out[3 * (size_t)i + d] = dir_in[3 * (size_t)i + d] * s;                     // "*iter *= interpolated"
+            dir_out[3 * (size_t)i + d] = dir_in[3 * (size_t)i + d] * sf;                    // "*iter *= interpolated"
         } else {
-            const int64_t nn = (int64_t)dir_in[3 * (size_t)i + d] * (int64_t)s, dd = 0x10000;
+            const int64_t nn = (int64_t)dir_in[3 * (size_t)i + d] * (int64_t)su, dd = 0x10000;
             const int64_t t = nn < 0 ? (nn - dd / 2) / dd : (nn + dd / 2) / dd;             // divRoundClosest
             if (t > 32767 || t < -32768) atomicOr(&err->normalize_overflow, 1u);
             dir_out[3 * (size_t)i + d] = (DirT)t;
