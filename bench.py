@@ -38,7 +38,7 @@ CONFIGS = {
     2: dict(N=256, R=512, gen="perspective", field="f32", name="256^3 fp32 field, 512x512 perspective rays"),
     3: dict(N=512, R=1024, gen="perspective", field="f32", name="512^3 fp32 field, 1024x1024 perspective rays"),
     4: dict(N=512, R=2048, gen="perspective", field="f32", name="512^3 fp32 field, 2048x2048 perspective rays"),
-    5: dict(N=1024, R=1024, gen="ortho", field="i16", opaque=True,
+    5: dict(N=1024, R=1024, gen="ortho", field="i16", lut=True,
             name="1024^3 uint8+LUT volume expanded to the int16 field, 1024x1024 ortho rays, opaque cores"),
     # small smoke-size config for quick checks
     0: dict(N=96, R=256, gen="perspective", field="f32", name="96^3 fp32 field, 256x256 perspective rays (smoke)"),
@@ -80,6 +80,24 @@ def synth_field_device(N, field, dev, opaque=False, seed=1234, nblobs=4, amp=0.5
             tr[sl] = torch.where(near, torch.zeros((), dtype=torch.int32, device=dev),
                                  torch.full((), -1, dtype=torch.int32, device=dev)).reshape(-1)
     return [B, B, B], d, tr
+
+
+def synth_density_device(N, dev, seed=1234, nblobs=4):
+    """workloads.uint8_density_and_lut evaluated on the GPU: uint8 density [N^3] (device tensor)."""
+    c = torch.tensor(W.blob_centres(N, seed, nblobs), dtype=torch.float64, device=dev)
+    a = 16.0 / (N * N)
+    dens = torch.empty(N * N * N, dtype=torch.uint8, device=dev)
+    y = torch.arange(N, dtype=torch.float64, device=dev)[None, :, None]
+    z = torch.arange(N, dtype=torch.float64, device=dev)[None, None, :]
+    CH = 8
+    for x0 in range(0, N, CH):
+        x1 = min(N, x0 + CH)
+        x = torch.arange(x0, x1, dtype=torch.float64, device=dev)[:, None, None]
+        n = torch.zeros((x1 - x0, N, N), dtype=torch.float64, device=dev)
+        for k in range(nblobs):
+            n = n + 0.5 * torch.exp(-((x - c[k, 0]) ** 2 + (y - c[k, 1]) ** 2 + (z - c[k, 2]) ** 2) * a)
+        dens[x0 * N * N:x1 * N * N] = torch.clamp(torch.round(n / (0.5 * nblobs) * 255.0 * 2.0), 0, 255).to(torch.uint8).reshape(-1)
+    return dens
 
 
 def make_rays(cfg, rank, world):
@@ -156,10 +174,23 @@ def main():
     cfg = CONFIGS[args.config]
     N = cfg["N"]
     t0 = time.time()
-    bounds, d, tr = synth_field_device(N, cfg["field"], dev, opaque=cfg.get("opaque", False))
-    torch.cuda.synchronize()
-    ftype = capi.VRT_F32 if cfg["field"] == "f32" else capi.VRT_I16
-    eng = capi.Engine.from_device(bounds, [x.data_ptr() for x in d], tr.data_ptr(), ftype, d[0].numel())
+    scene = None
+    if cfg.get("lut"):
+        # BASELINE config 5: uint8 density + 256-entry transfer function -> int16 field, all through the
+        # scene layer (vrt_scene_create_lut); the march is then timed on the scene's engine.
+        dens = synth_density_device(N, dev).cpu().numpy()
+        dd = np.arange(256, dtype=np.float64)
+        lut_ior = np.round((1.0 + dd / 510.0) * 65536).astype(np.uint32)
+        lut_tr = np.where(dd < 160, 0xFFFFFFFF, 0).astype(np.uint32)
+        scene = capi.Scene.from_lut([N, N, N], dens, lut_ior, lut_tr)
+        eng = scene.engine()
+        bounds = [N - 2] * 3
+        d = tr = None
+    else:
+        bounds, d, tr = synth_field_device(N, cfg["field"], dev, opaque=cfg.get("opaque", False))
+        torch.cuda.synchronize()
+        ftype = capi.VRT_F32 if cfg["field"] == "f32" else capi.VRT_I16
+        eng = capi.Engine.from_device(bounds, [x.data_ptr() for x in d], tr.data_ptr(), ftype, d[0].numel())
     log("field %s built on device in %.1f s (%.2f GB resident)" % (cfg["name"], time.time() - t0, eng.field_bytes / 1e9))
 
     sp, sd = make_rays(cfg, rank, world)
@@ -257,7 +288,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel_ms": kavg_ms, "algorithmic_bytes_per_ray_step": bytes_per_step},
     }
-    if args.cpu_seconds > 0:
+    if args.cpu_seconds > 0 and d is not None:
         host = [x.cpu().numpy() for x in d]
         tc_host = tr.cpu().numpy().view(np.uint32)
         import oracle

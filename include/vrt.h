@@ -57,7 +57,7 @@ typedef struct vrt_options {
     uint64_t max_cpu;        /* _max_cpu (256): kept for ABI parity; unused (no CPU path) */
     int32_t  device;         /* extension: HIP device ordinal, -1 = current device */
     int32_t  kernel;         /* extension: VRT_KERNEL_* selector, 0 = auto */
-    int32_t  sort_rays;      /* extension: 0 = auto, 1 = force tile ordering, -1 = keep caller order */
+    int32_t  sort_rays;      /* extension: 0 = auto, 1 = tile ordering, 2 = tile ordering longest-first, -1 = keep caller order */
     int32_t  slab_lds_bytes; /* extension: LDS bytes per wavefront for the slab kernel, 0 = default */
     int32_t  reserved[4];
 } vrt_options;

@@ -1,0 +1,9 @@
+#!/bin/bash
+# Build a development variant of the engine with the slab kernel's debug counters compiled in:
+#   tools/build_debug.sh  ->  tmp_libs/libvrt_stats.so   (use with VRT_LIB=... VRT_DEBUG_STATS=1)
+set -e
+cd "$(dirname "$0")/.."
+mkdir -p tmp_libs
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-slp-vectorize -DVRT_SLAB_STATS \
+    -o tmp_libs/libvrt_stats.so volumeraytracer_amd/csrc/vrt_engine.hip
+echo tmp_libs/libvrt_stats.so

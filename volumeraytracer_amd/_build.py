@@ -17,6 +17,9 @@ HIPCC_FLAGS = [
     # every fma in the march is written out; the compiler must not add or remove any
     # (bit parity with the reference's CPU build, see csrc/vrt_march.h)
     "-ffp-contract=off",
+    # packed fp32 (v_pk_*) issues at half the rate of scalar fp32 on gfx950 and drags hazard s_nops in
+    # (tools/ubench/valu_rate.hip): keep the march scalar
+    "-fno-slp-vectorize",
     "-Wall", "-Wno-unused-function",
 ]
 

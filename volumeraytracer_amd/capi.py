@@ -42,7 +42,8 @@ _lib = None
 
 
 def lib_path():
-    return _build.LIB
+    # VRT_LIB selects another build of the same library (A/B runs of kernel variants in one snapshot)
+    return os.environ.get("VRT_LIB") or _build.LIB
 
 
 def load():
@@ -134,10 +135,11 @@ def _type_of(dt):
 class Engine:
     """Owning handle on a vrt_engine (a field resident in HBM on one device)."""
 
-    def __init__(self, handle, field_type, bounds):
+    def __init__(self, handle, field_type, bounds, owned=True):
         self._h = handle
         self.field_type = field_type
         self.bounds = [int(b) for b in bounds]
+        self._owned = owned     # False: a view on the engine inside a Scene (the scene frees it)
 
     @classmethod
     def from_host(cls, bounds, diff, transl_cropped, options=None):
@@ -224,7 +226,7 @@ class Engine:
                                  C.byref(options) if options is not None else None))
 
     def close(self):
-        if self._h is not None and _lib is not None:
+        if self._h is not None and _lib is not None and self._owned:
             _lib.vrt_destroy(self._h)
         self._h = None
 
@@ -288,10 +290,10 @@ class Scene:
         self.bounds = [int(x) for x in bounds]
         return self
 
-    @property
-    def engine_handle(self):
-        """The seam-level vrt_handle inside the scene (owned by the scene)."""
-        return C.c_void_p(load().vrt_scene_engine(self._h))
+    def engine(self):
+        """Non-owning Engine view on the seam-level engine inside the scene (valid while the scene lives)."""
+        h = C.c_void_p(load().vrt_scene_engine(self._h))
+        return Engine(h, VRT_F32 if self.ior_type == VRT_F32 else VRT_I16, [b - 2 for b in self.bounds], owned=False)
 
     def trace_rays(self, start_position, start_direction, invscale, iterations, trace_paths=False,
                    minimum_brightness=0, normalize_length=True, options=None):

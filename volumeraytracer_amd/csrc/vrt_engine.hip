@@ -272,7 +272,7 @@ int trace_device_impl(vrt_engine *e, int dir_type, size_t nrays, const uint32_t 
     const bool sort = o.sort_rays > 0 || (o.sort_rays == 0 && nrays >= 4096);
     if (sort) {
         const uint32_t *order = nullptr;
-        hipError_t se = vrt::build_tile_order(d_sp, d_sd, dir_type, (uint32_t)nrays, e->sort_keys, e->sort_keys_alt,
+        hipError_t se = vrt::build_tile_order(d_sp, d_sd, dir_type, (uint32_t)nrays, e->B[0], e->B[1], e->B[2], o.sort_rays == 2 ? 1 : 0, e->sort_keys, e->sort_keys_alt,
                                               e->sort_vals, e->sort_vals_alt, e->sort_tmp, e->sort_bounds, s, &order);
         if (se != hipSuccess) return fail(se == hipErrorOutOfMemory ? VRT_ERR_OUT_OF_MEMORY : VRT_ERR_HIP,
                                           "ray tile ordering failed: %s", hipGetErrorString(se));

@@ -83,27 +83,30 @@ struct Ray {
 
 __device__ __forceinline__ bool march_step(Ray &r, const f4 (&c)[8], float invx, float invy, float invz)
 {
-    const float wrx = (float)(r.px & 0xFFFFu), wlx = (float)(0x10000u - (r.px & 0xFFFFu));
-    const float wry = (float)(r.py & 0xFFFFu), wly = (float)(0x10000u - (r.py & 0xFFFFu));
-    const float wrz = (float)(r.pz & 0xFFFFu), wlz = (float)(0x10000u - (r.pz & 0xFFFFu));
+    // wl = 0x10000 - wr is formed in float: both are integers below 2^17, so the subtraction is exact
+    // and equals the reference's (float)(0x10000 - multr) (.cu:145-153)
+    const float wrx = (float)(r.px & 0xFFFFu), wlx = 65536.0f - wrx;
+    const float wry = (float)(r.py & 0xFFFFu), wly = 65536.0f - wry;
+    const float wrz = (float)(r.pz & 0xFFFFu), wlz = 65536.0f - wrz;
 
     // opacity channel (.cu:343): only the sign of the interpolated w matters.  If all eight
     // corner values are <= 0 every product and fma below is <= 0; if all are > 0 the result is
     // > 0 (the (0,0,0) corner has weight >= 1).  Only mixed neighbourhoods need the arithmetic.
-    const float wmax = fmaxf(fmaxf(fmaxf(c[0].w, c[1].w), fmaxf(c[2].w, c[3].w)),
-                             fmaxf(fmaxf(c[4].w, c[5].w), fmaxf(c[6].w, c[7].w)));
-    if (wmax > 0.0f) {
-        const float wmin = fminf(fminf(fminf(c[0].w, c[1].w), fminf(c[2].w, c[3].w)),
-                                 fminf(fminf(c[4].w, c[5].w), fminf(c[6].w, c[7].w)));
-        if (wmin > 0.0f) return true;
+    // The w values are integers stored as floats (engine-built: never NaN, never -0.0), so a value is
+    // > 0.0f exactly when its bit pattern is > 0 as int32: "some corner positive" is an integer max > 0
+    // and "all corners positive" an integer min > 0 -- no float canonicalisation needed.
+    const int32_t wi[8] = {__float_as_int(c[0].w), __float_as_int(c[1].w), __float_as_int(c[2].w), __float_as_int(c[3].w),
+                           __float_as_int(c[4].w), __float_as_int(c[5].w), __float_as_int(c[6].w), __float_as_int(c[7].w)};
+    const int32_t wmax = max(max(max(wi[0], wi[1]), max(wi[2], wi[3])), max(max(wi[4], wi[5]), max(wi[6], wi[7])));
+    if (wmax > 0) {                                   // some corner has w > 0.0f (bit pattern of +0.0 is 0)
+        const int32_t wmin = min(min(min(wi[0], wi[1]), min(wi[2], wi[3])), min(min(wi[4], wi[5]), min(wi[6], wi[7])));
+        if (wmin > 0) return true;
         float a00 = lerp_(c[0].w, wlx, c[4].w, wrx), a01 = lerp_(c[1].w, wlx, c[5].w, wrx);
         float a10 = lerp_(c[2].w, wlx, c[6].w, wrx), a11 = lerp_(c[3].w, wlx, c[7].w, wrx);
         float b0 = lerp_(a00, wly, a10, wry), b1 = lerp_(a01, wly, a11, wry);
         float w = lerp_(b0, wlz, b1, wrz) * (1.0f / 0x1000000000000p0f);
         if (w > 0.0f) return true;
     }
-    // NaN in the w channel: fmaxf drops NaNs, so a NaN corner can hide here only if the
-    // reference's result would be NaN (not > 0) as well -- same decision.
 
     float g[3];
     {

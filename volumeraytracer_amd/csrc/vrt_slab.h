@@ -42,7 +42,11 @@ enum { kStatRounds = 0, kStatPlannedK, kStatLdsWaveSteps, kStatDirectRounds, kSt
        kStatEarlyExit, kStatCount };
 __device__ __forceinline__ void stat_add(const MarchParams &p, int which, unsigned long long v)
 {
+#ifdef VRT_SLAB_STATS      // development builds only (tools/build_debug.sh): keeps the branches out of the hot loop
     if (p.stats && (threadIdx.x & 63u) == 0) atomicAdd(p.stats + which, v);
+#else
+    (void)p; (void)which; (void)v;
+#endif
 }
 
 struct Brick {
@@ -82,13 +86,29 @@ __device__ __forceinline__ uint32_t plan_brick(const PlanIn &in, int K, const ui
     return big ? cap + 1 : vol;
 }
 
-template <typename FieldT>
-__device__ __forceinline__ void gather_lds(const typename FieldTraits<FieldT>::vox *seg, uint32_t base, uint32_t sy,
-                                           uint32_t sx, f4 (&c)[8])
+// The LDS brick always holds fp32 voxels: an int16 field is converted once while it is staged
+// (exact: (float)int16), not 32 times per step.
+__device__ __forceinline__ vox_f32 to_f32_vox(const vox_f32 &v) { return v; }
+__device__ __forceinline__ vox_f32 to_f32_vox(const vox_i16 &v)
 {
-    using vox = typename FieldTraits<FieldT>::vox;
-    const vox *b = seg + base;
-    vox v[8];
+    vox_f32 o;
+    o.x = (float)v.x; o.y = (float)v.y; o.z = (float)v.z; o.w = (float)v.w;
+    return o;
+}
+
+#ifndef VRT_SLAB_LDS_F32   // default: keep the field's own voxel type in LDS (measured: config 5 is 2% faster than fp32-in-LDS)
+template <typename FieldT> struct LdsVox { using type = typename FieldTraits<FieldT>::vox; };
+template <typename V> __device__ __forceinline__ V to_lds_vox(const V &v) { return v; }
+#else
+template <typename FieldT> struct LdsVox { using type = vox_f32; };
+template <typename V> __device__ __forceinline__ vox_f32 to_lds_vox(const V &v) { return to_f32_vox(v); }
+#endif
+
+template <typename LV>
+__device__ __forceinline__ void gather_lds(const LV *seg, uint32_t base, uint32_t sy, uint32_t sx, f4 (&c)[8])
+{
+    const LV *b = seg + base;
+    LV v[8];
     v[0] = b[0];       v[1] = b[1];
     v[2] = b[sy];      v[3] = b[sy + 1];
     v[4] = b[sx];      v[5] = b[sx + 1];
@@ -97,7 +117,7 @@ __device__ __forceinline__ void gather_lds(const typename FieldTraits<FieldT>::v
     for (int k = 0; k < 8; ++k) cvt_vox(v[k], c[k]);
 }
 
-// VPL = voxels staged per lane at most; the wave's LDS segment holds 64*VPL voxels.
+// VPL = voxels staged per lane at most; the wave's LDS segment holds 64*VPL fp32 voxels (16 B each).
 // OCC = waves per SIMD the register allocator must allow (launch-bounds second argument).
 template <typename FieldT, typename DirT, int VPL, int OCC>
 __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(const MarchParams p)
@@ -106,7 +126,8 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
     constexpr uint32_t kCap = 64u * VPL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t wave = threadIdx.x >> 6;
-    vox *seg = (vox *)smem + (size_t)wave * kCap;
+    using lvox = typename LdsVox<FieldT>::type;
+    lvox *seg = (lvox *)smem + (size_t)wave * kCap;
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
@@ -121,14 +142,14 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
     const float invx = p.invx, invy = p.invy, invz = p.invz;
 
     // `it` is the reference's remaining-iterations counter (.cu:333-351): it drops by one per
-    // completed step and the ray stops at it == 0, on leaving the field, or on w > 0; the
-    // value at that moment is raydata._iterations.
-    uint32_t it = p.iterations - 1;
-    bool done = !have;
+    // completed step and the ray stops at it == 0, on leaving the field, or on w > 0; the value at
+    // that moment is raydata._iterations.  A ray stopped by the w > 0 test parks that value in
+    // `rem_w` and zeroes `it`, so "it > 0 and inside the field" is the only liveness predicate.
+    uint32_t it = have ? p.iterations - 1 : 0u;
+    uint32_t rem_w = 0xFFFFFFFFu;
 
     for (;;) {
-        bool live = !done && it > 0 && in_field(r, bx1, by1, bz1);
-        done = !live;
+        const bool live = it > 0 && in_field(r, bx1, by1, bz1);
         if (__ballot(live) == 0ull) break;              // wave early-out: every lane has terminated
 
         // ---- plan -------------------------------------------------------------------------
@@ -177,14 +198,13 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
             // ---- incoherent wave: gather from global memory for a few steps, then re-plan ----
             stat_add(p, kStatDirectRounds, 1);
             for (int k = 0; k < kSlabDirectSteps; ++k) {
-                live = !done && it > 0 && in_field(r, bx1, by1, bz1);
-                done = !live;
-                if (__ballot(live) == 0ull) break;
+                const bool alive = it > 0 && in_field(r, bx1, by1, bz1);
+                if (__ballot(alive) == 0ull) break;
                 stat_add(p, kStatDirectWaveSteps, 1);
-                if (live) {
+                if (alive) {
                     f4 c[8];
                     gather_global<FieldT>(f, r, p.By, p.Bz, c);
-                    if (march_step(r, c, invx, invy, invz)) done = true; else --it;
+                    if (march_step(r, c, invx, invy, invz)) { rem_w = it; it = 0; } else --it;
                 }
             }
             continue;
@@ -216,7 +236,7 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
 #pragma unroll
             for (int j = 0; j < VPL; ++j) {
                 const uint32_t v = lane + 64u * j;
-                if (v < vol) seg[v] = tmp[j];
+                if (v < vol) seg[v] = to_lds_vox(tmp[j]);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -230,32 +250,32 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
             for (int k = 0; k < K; ++k) {
                 const uint32_t cx = (r.px >> 16) - lox, cy = (r.py >> 16) - loy, cz = (r.pz >> 16) - loz;
                 const bool inb = cx < ex1 && cy < ey1 && cz < ez1;   // cell and its +1 neighbours are staged
-                bool want = !done && it > 0;
-                if (__ballot(want && !inb) != 0ull) {                // rare: some lane is outside the brick
-                    // the brick is clipped to the field, so a lane that left the field is outside it too: retire those
-                    if (want && !inb && !in_field(r, bx1, by1, bz1)) { done = true; want = false; }
-                    if (__ballot(want && !inb) != 0ull) { stat_add(p, kStatEarlyExit, 1); break; }   // a live ray left the brick: re-plan
+                const bool pos = it > 0;
+                if (__ballot(pos && !inb) != 0ull) {                 // rare: some lane is outside the brick
+                    // the brick is clipped to the field, so a ray that left the field is outside the brick too
+                    // and simply stops marching; a ray still inside the field forces a new plan
+                    if (__ballot(pos && !inb && in_field(r, bx1, by1, bz1)) != 0ull) { stat_add(p, kStatEarlyExit, 1); break; }
                 }
-                if (__ballot(want) == 0ull) break;
+                const bool alive = pos && inb;                       // inside the brick => inside the field
+                if (__ballot(alive) == 0ull) break;
                 stat_add(p, kStatLdsWaveSteps, 1);
-                if (want) {                                          // inside the brick => inside the field
+                if (alive) {
                     f4 c[8];
-                    gather_lds<FieldT>(seg, (cx * ey + cy) * ez + cz, sy, sx, c);
-                    if (march_step(r, c, invx, invy, invz)) done = true; else --it;
+                    gather_lds(seg, __umul24(__umul24(cx, ey) + cy, ez) + cz, sy, sx, c);
+                    if (march_step(r, c, invx, invy, invz)) { rem_w = it; it = 0; } else --it;
                 }
             }
         }
     }
-    if (have) store_ray<DirT>(p, ray, r, it);
+    if (have) store_ray<DirT>(p, ray, r, rem_w != 0xFFFFFFFFu ? rem_w : it);
 }
 
 template <typename FieldT, typename DirT, int VPL, int OCC>
 hipError_t launch_slab_vpl(const MarchParams &p, hipStream_t s)
 {
-    using vox = typename FieldTraits<FieldT>::vox;
     const unsigned threads = 64 * kSlabWavesPerBlock;
     const unsigned grid = (p.nrays + threads - 1) / threads;
-    const size_t lds = sizeof(vox) * 64 * VPL * kSlabWavesPerBlock;
+    const size_t lds = sizeof(typename LdsVox<FieldT>::type) * 64 * VPL * kSlabWavesPerBlock;
     k_march_slab<FieldT, DirT, VPL, OCC><<<grid, threads, lds, s>>>(p);
     return hipGetLastError();
 }
@@ -264,9 +284,8 @@ hipError_t launch_slab_vpl(const MarchParams &p, hipStream_t s)
 template <typename FieldT, typename DirT>
 hipError_t launch_slab(MarchParams p, bool /*path*/, int /*num_cu*/, hipStream_t s)
 {
-    using vox = typename FieldTraits<FieldT>::vox;
     const uint32_t want = p.slab_lds_bytes ? p.slab_lds_bytes : 6144u;   // measured best on config 3
-    const uint32_t vpl = want / (64u * (uint32_t)sizeof(vox));
+    const uint32_t vpl = want / (64u * (uint32_t)sizeof(typename LdsVox<FieldT>::type));
     // LDS per wave and register budget are chosen together: 160 KiB LDS / CU and 512 VGPRs / SIMD lane
     if (vpl <= 4) return launch_slab_vpl<FieldT, DirT, 4, 8>(p, s);
     if (vpl <= 5) return launch_slab_vpl<FieldT, DirT, 5, 8>(p, s);

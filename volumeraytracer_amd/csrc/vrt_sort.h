@@ -51,10 +51,14 @@ __global__ __launch_bounds__(256) void k_ray_bounds(const uint32_t *pos, uint32_
 }
 
 // key layout, most significant first:
-//   dom:3 | depth bin:8 | tile u:11 | tile v (serpentine):11 | row inside tile:4 | v fine:27
+//   work bucket:3 | dom:3 | depth bin:8 | tile u:11 | tile v (serpentine):11 | row inside tile:4 | v fine:24
+// The work bucket orders wavefronts longest-first (LPT): the straight-line distance to the field
+// boundary estimates a ray's step count, so the wavefronts dispatched last are the short ones and
+// the end of the launch does not wait on a full-length straggler.
 template <typename DirT>
 __global__ __launch_bounds__(256) void k_tile_keys(const uint32_t *pos, const DirT *dir, uint32_t n,
-                                                   const RayBounds *rb, uint64_t *keys, uint32_t *vals)
+                                                   const RayBounds *rb, uint32_t Bx, uint32_t By, uint32_t Bz,
+                                                   int lpt, uint64_t *keys, uint32_t *vals)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -85,17 +89,33 @@ __global__ __launch_bounds__(256) void k_tile_keys(const uint32_t *pos, const Di
     row = row > 15u ? 15u : row;
     uint32_t wb = (uint32_t)((float)(p[aw] - rb->lo[aw]) * fminf(invW, 255.0f / rw));
     wb = wb > 255u ? 255u : wb;
-    uint32_t vf = (p[av] - rb->lo[av]) >> 5;
-    vf = vf > 0x7FFFFFFu ? 0x7FFFFFFu : vf;
-    if (tu & 1u) { tv = 2047u - tv; vf = 0x7FFFFFFu - vf; }      // serpentine: odd tile columns run backwards
-    keys[i] = ((uint64_t)dom << 61) | ((uint64_t)wb << 53) | ((uint64_t)tu << 42) | ((uint64_t)tv << 31) |
-              ((uint64_t)row << 27) | (uint64_t)vf;
+    uint32_t vf = (p[av] - rb->lo[av]) >> 8;
+    vf = vf > 0xFFFFFFu ? 0xFFFFFFu : vf;
+    if (tu & 1u) { tv = 2047u - tv; vf = 0xFFFFFFu - vf; }       // serpentine: odd tile columns run backwards
+    // straight-line exit distance (voxels) inside [0, B-1]^3, relative to the longest axis
+    const float d3[3] = {dx, dy, dz};
+    const float hi3[3] = {(float)(Bx - 1) * 65536.0f, (float)(By - 1) * 65536.0f, (float)(Bz - 1) * 65536.0f};
+    float t = 3.0e38f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float pd = (float)p[d];
+        if (d3[d] > 0.0f) t = fminf(t, (hi3[d] - pd) / d3[d]);
+        else if (d3[d] < 0.0f) t = fminf(t, -pd / d3[d]);
+    }
+    const float len = t < 3.0e38f ? t * sqrtf(dx * dx + dy * dy + dz * dz) : 0.0f;
+    const float ref = fmaxf(fmaxf(hi3[0], hi3[1]), hi3[2]);
+    int bucket = (int)(len * 6.0f / ref);                        // 0 (short) .. 7 (longer than the longest axis)
+    bucket = bucket < 0 ? 0 : (bucket > 7 ? 7 : bucket);
+    if (!lpt) bucket = 7;
+    keys[i] = ((uint64_t)(7 - bucket) << 61) | ((uint64_t)dom << 58) | ((uint64_t)wb << 50) | ((uint64_t)tu << 39) |
+              ((uint64_t)tv << 28) | ((uint64_t)row << 24) | (uint64_t)vf;
     vals[i] = i;
 }
 
 // grow-only device buffer interface expected from the caller (see DevBuf in vrt_engine.hip)
 template <typename Buf>
-hipError_t build_tile_order(const uint32_t *d_pos, const void *d_dir, int dir_is_i16, uint32_t n, Buf &keys,
+hipError_t build_tile_order(const uint32_t *d_pos, const void *d_dir, int dir_is_i16, uint32_t n,
+                            uint32_t Bx, uint32_t By, uint32_t Bz, int lpt, Buf &keys,
                             Buf &keys_alt, Buf &vals, Buf &vals_alt, Buf &tmp, Buf &bounds, hipStream_t s,
                             const uint32_t **order_out)
 {
@@ -110,8 +130,8 @@ hipError_t build_tile_order(const uint32_t *d_pos, const void *d_dir, int dir_is
     const unsigned rgrid = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
     k_ray_bounds<<<rgrid, 256, 0, s>>>(d_pos, n, rb);
     const unsigned grid = (n + 255) / 256;
-    if (dir_is_i16) k_tile_keys<int16_t><<<grid, 256, 0, s>>>(d_pos, (const int16_t *)d_dir, n, rb, (uint64_t *)keys.p, (uint32_t *)vals.p);
-    else            k_tile_keys<float><<<grid, 256, 0, s>>>(d_pos, (const float *)d_dir, n, rb, (uint64_t *)keys.p, (uint32_t *)vals.p);
+    if (dir_is_i16) k_tile_keys<int16_t><<<grid, 256, 0, s>>>(d_pos, (const int16_t *)d_dir, n, rb, Bx, By, Bz, lpt, (uint64_t *)keys.p, (uint32_t *)vals.p);
+    else            k_tile_keys<float><<<grid, 256, 0, s>>>(d_pos, (const float *)d_dir, n, rb, Bx, By, Bz, lpt, (uint64_t *)keys.p, (uint32_t *)vals.p);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     size_t tmp_bytes = 0;
     e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const uint64_t *)keys.p, (uint64_t *)keys_alt.p,
