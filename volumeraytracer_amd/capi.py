@@ -185,7 +185,7 @@ class Engine:
         buf = (C.c_ulonglong * 16)()
         check(load().vrt_engine_debug_stats(self._h, buf, 16))
         names = ("rounds", "planned_K_sum", "lds_wave_steps", "direct_rounds", "direct_wave_steps", "vox_staged",
-                 "early_exit")
+                 "early_exit", "_7", "fb_ex_sum", "fb_ey_sum", "fb_ez_sum", "fb_live_lanes_sum", "fb_steps_done_sum")
         return dict(zip(names, [int(x) for x in buf]))
 
     def last_march_ms(self):

@@ -58,6 +58,15 @@ __device__ __forceinline__ int32_t round_to_i32(float x)
     return r;
 }
 
+// roundf(x) as uint32 two's complement for |x| < 2^30 (exact, see march_step)
+__device__ __forceinline__ uint32_t round_small_i32(float x)
+{
+    const float a = __builtin_fabsf(x) + __builtin_fabsf(x);
+    const uint32_t m = ((uint32_t)a + 1u) >> 1;
+    const uint32_t sgn = (uint32_t)((int32_t)__float_as_uint(x) >> 31);   // 0 or 0xFFFFFFFF
+    return (m ^ sgn) - sgn;
+}
+
 // ---- voxel pair loads: voxel z and z+1 at one (x,y), as 2 x f4 --------------------------
 
 typedef float   vox_f32 __attribute__((ext_vector_type(4)));   // 16 B: {dx, dy, dz, w}
@@ -124,9 +133,19 @@ __device__ __forceinline__ bool march_step(Ray &r, const f4 (&c)[8], float invx,
     r.dz = fma_(g[2], invz, r.dz);
     const float dot = fma_(r.dz, r.dz, fma_(r.dx, r.dx, r.dy * r.dy));
     const float ilen = 0x42000000p0f / dot;                 // IEEE divide (.cu:346)
-    r.px += (uint32_t)round_to_i32((r.dx * invx) * ilen);   // .cu:347
-    r.py += (uint32_t)round_to_i32((r.dy * invy) * ilen);
-    r.pz += (uint32_t)round_to_i32((r.dz * invz) * ilen);
+    const float sx = (r.dx * invx) * ilen, sy = (r.dy * invy) * ilen, sz = (r.dz * invz) * ilen;   // .cu:347
+    if (fmaxf(fmaxf(__builtin_fabsf(sx), __builtin_fabsf(sy)), __builtin_fabsf(sz)) < 1073741824.0f) {
+        // |s| < 2^30 (always, unless the direction has collapsed): roundf by integers.  2|s| is exact,
+        // its truncation t keeps the half bit, so round-half-away(|s|) == (t + 1) >> 1; the sign is
+        // applied as two's complement.  Same value as round_to_i32 below, ten VALU ops fewer per step.
+        r.px += round_small_i32(sx);
+        r.py += round_small_i32(sy);
+        r.pz += round_small_i32(sz);
+    } else {                                                // includes NaN: x86 cvttss2si semantics
+        r.px += (uint32_t)round_to_i32(sx);
+        r.py += (uint32_t)round_to_i32(sy);
+        r.pz += (uint32_t)round_to_i32(sz);
+    }
     return false;
 }
 

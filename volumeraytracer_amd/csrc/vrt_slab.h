@@ -197,6 +197,11 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
         if (vol > kCap || bk.e[0] < 2 || bk.e[1] < 2 || bk.e[2] < 2) {
             // ---- incoherent wave: gather from global memory for a few steps, then re-plan ----
             stat_add(p, kStatDirectRounds, 1);
+#ifdef VRT_SLAB_STATS
+            stat_add(p, 8, bk.e[0]); stat_add(p, 9, bk.e[1]); stat_add(p, 10, bk.e[2]);      // fallback brick extents (K = 1)
+            stat_add(p, 11, (unsigned long long)__popcll(__ballot(live)));                    // live lanes at fallback
+            stat_add(p, 12, (unsigned long long)(p.iterations - 1 - sgpr(__ockl_wfred_max_u32(live ? it : 0u))));  // steps done (min over lanes)
+#endif
             for (int k = 0; k < kSlabDirectSteps; ++k) {
                 const bool alive = it > 0 && in_field(r, bx1, by1, bz1);
                 if (__ballot(alive) == 0ull) break;
