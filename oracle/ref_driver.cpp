@@ -162,4 +162,29 @@ int ref_build_i16(const size_t *bounds, const uint32_t *ior, const uint32_t *tr,
                   int16_t *dx, int16_t *dy, int16_t *dz, uint32_t *tc, int32_t *ior_log)
 { return scene_build<ior_t, iorlog_t, diff_t>(bounds, ior, tr, nvox, dx, dy, dz, tc, ior_log); }
 
+/* write debug_scene_instance / debug_ray_instance with the reference's own serializer
+ * (image_util.cpp:75-92, image_util.h:236-246) -- golden files for the wire-format tests */
+int ref_write_instances_i16(const char *scene_path, const char *ray_path, const size_t *bounds, const uint32_t *ior,
+                            const uint32_t *tr, size_t nvox, size_t nrays, const uint32_t *sp, const int16_t *sd,
+                            const float *inv, uint32_t min_brightness, uint32_t iters, int trace_path, int normalize)
+{
+    try {
+        RayTraceSceneInstance<ior_t> sc;
+        sc._bound_vec.assign(bounds, bounds + 3);
+        sc._ior.assign(ior, ior + nvox);
+        sc._translucency.assign(tr, tr + nvox);
+        std::ofstream f1(scene_path, std::ios::binary);
+        SERIALIZE::write_value(f1, sc);
+        f1.close();
+        std::vector<pos_t> vsp(sp, sp + 3 * nrays);
+        std::vector<dir_t> vsd(sd, sd + 3 * nrays);
+        std::vector<float> vinv(inv, inv + 3);
+        RayTraceRayInstanceRef<dir_t> ray(vsp, vsd, vinv, min_brightness, iters, trace_path != 0, normalize != 0);
+        std::ofstream f2(ray_path, std::ios::binary);
+        SERIALIZE::write_value(f2, ray);
+        f2.close();
+        return 0;
+    } catch (std::exception const &e) { g_err = e.what(); return -1; }
+}
+
 }  // extern "C"

@@ -1,0 +1,65 @@
+"""GPU (-m gpu): BASELINE config 3 at full size (512^3 fp32 field, 1024x1024 perspective rays, the bench
+workload) through size-independent properties: the two kernels agree bit-for-bit on every ray under
+different ray orders, device-pointer and host-pointer entry points agree, and an evenly strided
+sample of rays matches the oracle bit-for-bit."""
+import numpy as np
+import pytest
+
+import oracle
+from volumeraytracer_amd import capi, distributed as D
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config3_full_size_properties():
+    torch = pytest.importorskip("torch")
+    import bench
+    cfg = bench.CONFIGS[3]
+    dev = torch.device("cuda", 0)
+    bounds, d, tr = bench.synth_field_device(cfg["N"], cfg["field"], dev)
+    torch.cuda.synchronize()
+    eng = capi.Engine.from_device(bounds, [x.data_ptr() for x in d], tr.data_ptr(), capi.VRT_F32, d[0].numel())
+    sp, sd = bench.make_rays(cfg, 0, 1)
+    n = sp.size // 3
+    d_sp = torch.from_numpy(sp.view(np.int32)).to(dev)
+    d_sd = torch.from_numpy(sd).to(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run(kernel, sort):
+        rec = D.alloc_record(n, dev)
+        ep, ed, ei, rl = D.record_views(rec, n)
+        eng.trace_device(capi.VRT_F32, n, d_sp.data_ptr(), d_sd.data_ptr(), ep.data_ptr(), ed.data_ptr(), ei.data_ptr(),
+                         rl.data_ptr(), [1, 1, 1], 100000, stream=stream,
+                         options=capi.default_options(kernel=kernel, sort_rays=sort))
+        torch.cuda.synchronize()
+        return rec.cpu().numpy()
+
+    a = run(capi.KERNEL_SLAB, 1)
+    assert np.array_equal(a, run(capi.KERNEL_DIRECT, -1)), "slab (tile order) vs direct (caller order)"
+    assert np.array_equal(a, run(capi.KERNEL_SLAB, 2)), "longest-first order"
+    assert np.array_equal(a, run(capi.KERNEL_SLAB, -1)), "slab in caller order"
+    ep, ed, ei, rl = a[:3 * n], a[3 * n:6 * n], a[6 * n:7 * n], a[7 * n:]
+    assert np.all(rl.view(np.uint32) == 0xFFFFFFFF)
+    steps = ei.view(np.uint32).astype(np.int64)
+    assert steps.min() > 500 and steps.max() < 100000          # transparent scene: every ray leaves the field
+    B = np.array(bounds, np.int64)
+    cell = ep.view(np.uint32).reshape(-1, 3).astype(np.int64) >> 16
+    assert np.all(np.any((cell >= B - 1) | (cell > 60000), axis=1)), "every ray ended outside the field"
+
+    # host-pointer entry point on a band of rays == device-pointer results
+    band = slice(0, 3 * 4096)
+    h = eng.trace(sp[band], sd[band], [1, 1, 1], 100000)
+    assert np.array_equal(h["end_position"], ep.view(np.uint32)[band])
+    assert np.array_equal(h["end_iteration"], ei.view(np.uint32)[:4096])
+
+    # oracle on an evenly strided sample
+    host = [x.cpu().numpy() for x in d]
+    field = oracle.port.interleave(host[0], host[1], host[2], tr.cpu().numpy().view(np.uint32))
+    del host
+    idx = np.linspace(0, n - 1, 3000).astype(np.int64)
+    want = oracle.port.trace(field, bounds, sp.reshape(-1, 3)[idx].reshape(-1), sd.reshape(-1, 3)[idx].reshape(-1),
+                             [1, 1, 1], 100000)
+    assert np.array_equal(want["end_position"].reshape(-1, 3), ep.view(np.uint32).reshape(-1, 3)[idx])
+    assert np.array_equal(want["end_direction"].view(np.uint32).reshape(-1, 3), ed.view(np.uint32).reshape(-1, 3)[idx])
+    assert np.array_equal(want["end_iteration"], ei.view(np.uint32)[idx])
+    eng.close()

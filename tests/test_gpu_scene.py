@@ -118,3 +118,18 @@ def test_lut_scene_golden(golden_dir, tag):
         out2 = sc2.trace_rays(g["start_position"], g["start_direction"], g["invscale"], int(g["iterations"]))
     for k in KEYS:
         assert _same(out2[k], g[k]), k
+
+
+def test_replay_reference_dump_files(golden_dir, capsys):
+    """Row f-4: replay the reference-written debug_scene_instance / debug_ray_instance on the GPU
+    (the raytrace_test.cpp CLI) and compare with the reference's outputs for those rays."""
+    from volumeraytracer_amd import replay
+    g = np.load(os.path.join(golden_dir, "L4_scene_i16.npz"))
+    sc, ry, out = replay.replay(os.path.join(golden_dir, "debug_scene_instance"),
+                                os.path.join(golden_dir, "debug_ray_instance"))
+    assert np.array_equal(out["end_position"], g["end_position"][:192])
+    assert np.array_equal(out["end_direction"], g["end_direction"][:192])
+    assert np.array_equal(out["end_iteration"], g["end_iteration"][:64])
+    assert replay.main([os.path.join(golden_dir, "debug_scene_instance"), os.path.join(golden_dir, "debug_ray_instance")]) == 0
+    text = capsys.readouterr().out
+    assert "begin " in text and ("end " + " ".join(str(int(x)) for x in g["end_position"][:192])) in text

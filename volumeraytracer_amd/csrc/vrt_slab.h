@@ -32,7 +32,10 @@ extern "C" __device__ int __ockl_wfred_max_i32(int);
 namespace vrt {
 
 constexpr int kSlabWavesPerBlock = 4;
-constexpr int kSlabMaxK = 192;          // longest planned round, steps
+#ifndef VRT_SLAB_MAXK
+#define VRT_SLAB_MAXK 192
+#endif
+constexpr int kSlabMaxK = VRT_SLAB_MAXK;   // longest planned round, steps
 constexpr int kSlabDirectSteps = 16;    // global-gather steps for a wave that fits no brick
 
 __device__ __forceinline__ uint32_t sgpr(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
