@@ -288,19 +288,25 @@ hipError_t launch_slab_vpl(const MarchParams &p, hipStream_t s)
     return hipGetLastError();
 }
 
-// slab_lds_bytes selects the LDS segment per wave: 0 = default.
+// slab_lds_bytes selects the LDS segment per wave (0 = default).  The voxel count per lane and the
+// register budget (waves per SIMD the allocator must allow) both follow from the byte size:
+// 160 KiB LDS / CU and 512 VGPRs per SIMD lane give 8 waves/SIMD at <= 5 KiB, 6 at 6 KiB, 5 at 8 KiB ...
+template <typename FieldT, typename DirT, int BYTES, int OCC>
+hipError_t launch_slab_bytes(const MarchParams &p, hipStream_t s)
+{
+    return launch_slab_vpl<FieldT, DirT, BYTES / (64 * (int)sizeof(typename LdsVox<FieldT>::type)), OCC>(p, s);
+}
+
 template <typename FieldT, typename DirT>
 hipError_t launch_slab(MarchParams p, bool /*path*/, int /*num_cu*/, hipStream_t s)
 {
-    const uint32_t want = p.slab_lds_bytes ? p.slab_lds_bytes : 6144u;   // measured best on config 3
-    const uint32_t vpl = want / (64u * (uint32_t)sizeof(typename LdsVox<FieldT>::type));
-    // LDS per wave and register budget are chosen together: 160 KiB LDS / CU and 512 VGPRs / SIMD lane
-    if (vpl <= 4) return launch_slab_vpl<FieldT, DirT, 4, 8>(p, s);
-    if (vpl <= 5) return launch_slab_vpl<FieldT, DirT, 5, 8>(p, s);
-    if (vpl <= 6) return launch_slab_vpl<FieldT, DirT, 6, 6>(p, s);
-    if (vpl <= 8) return launch_slab_vpl<FieldT, DirT, 8, 5>(p, s);
-    if (vpl <= 12) return launch_slab_vpl<FieldT, DirT, 12, 3>(p, s);
-    return launch_slab_vpl<FieldT, DirT, 16, 2>(p, s);
+    const uint32_t want = p.slab_lds_bytes ? p.slab_lds_bytes : 6144u;   // measured best on configs 3 and 5
+    if (want <= 4096) return launch_slab_bytes<FieldT, DirT, 4096, 8>(p, s);
+    if (want <= 5120) return launch_slab_bytes<FieldT, DirT, 5120, 8>(p, s);
+    if (want <= 6144) return launch_slab_bytes<FieldT, DirT, 6144, 6>(p, s);
+    if (want <= 8192) return launch_slab_bytes<FieldT, DirT, 8192, 5>(p, s);
+    if (want <= 12288) return launch_slab_bytes<FieldT, DirT, 12288, 3>(p, s);
+    return launch_slab_bytes<FieldT, DirT, 16384, 2>(p, s);
 }
 
 }  // namespace vrt
