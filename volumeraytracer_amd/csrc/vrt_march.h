@@ -90,7 +90,10 @@ struct Ray {
     float dx, dy, dz;        // internal scale, unit 1.0 == 65536 (.cu:328-331)
 };
 
-__device__ __forceinline__ bool march_step(Ray &r, const f4 (&c)[8], float invx, float invy, float invz)
+// check_w == false promises that none of the eight corners has w > 0 (the slab kernel knows this for a
+// whole brick from a ballot taken while staging it), so the opacity test cannot fire and is skipped.
+__device__ __forceinline__ bool march_step(Ray &r, const f4 (&c)[8], float invx, float invy, float invz,
+                                           bool check_w = true)
 {
     // wl = 0x10000 - wr is formed in float: both are integers below 2^17, so the subtraction is exact
     // and equals the reference's (float)(0x10000 - multr) (.cu:145-153)
@@ -106,7 +109,7 @@ __device__ __forceinline__ bool march_step(Ray &r, const f4 (&c)[8], float invx,
     // and "all corners positive" an integer min > 0 -- no float canonicalisation needed.
     const int32_t wi[8] = {__float_as_int(c[0].w), __float_as_int(c[1].w), __float_as_int(c[2].w), __float_as_int(c[3].w),
                            __float_as_int(c[4].w), __float_as_int(c[5].w), __float_as_int(c[6].w), __float_as_int(c[7].w)};
-    const int32_t wmax = max(max(max(wi[0], wi[1]), max(wi[2], wi[3])), max(max(wi[4], wi[5]), max(wi[6], wi[7])));
+    const int32_t wmax = check_w ? max(max(max(wi[0], wi[1]), max(wi[2], wi[3])), max(max(wi[4], wi[5]), max(wi[6], wi[7]))) : 0;
     if (wmax > 0) {                                   // some corner has w > 0.0f (bit pattern of +0.0 is 0)
         const int32_t wmin = min(min(min(wi[0], wi[1]), min(wi[2], wi[3])), min(min(wi[4], wi[5]), min(wi[6], wi[7])));
         if (wmin > 0) return true;

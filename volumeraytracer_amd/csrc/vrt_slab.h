@@ -222,6 +222,7 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
         stat_add(p, kStatPlannedK, (unsigned long long)K);
         stat_add(p, kStatVoxStaged, vol);
         const uint32_t ey = bk.e[1], ez = bk.e[2];
+        bool brick_has_w;
         // ---- stage: brick -> LDS ----------------------------------------------------------
         {
             // exact division by the wave-uniform extents via 2^32 reciprocals (v < 2^16)
@@ -241,11 +242,14 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                 tmp[j] = g0[(size_t)lx * gsx + (size_t)ly * gsy + lz];
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");    // previous round's LDS reads are done
+            bool wpos = false;
 #pragma unroll
             for (int j = 0; j < VPL; ++j) {
                 const uint32_t v = lane + 64u * j;
+                wpos |= tmp[j].w > 0;                                 // lanes past the end re-read voxel 0: harmless
                 if (v < vol) seg[v] = to_lds_vox(tmp[j]);
             }
+            brick_has_w = __ballot(wpos) != 0ull;                     // wave-uniform: any opaque-ish voxel staged?
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                 if (alive) {
                     f4 c[8];
                     gather_lds(seg, __umul24(__umul24(cx, ey) + cy, ez) + cz, sy, sx, c);
-                    if (march_step(r, c, invx, invy, invz)) { rem_w = it; it = 0; } else --it;
+                    if (march_step(r, c, invx, invy, invz, brick_has_w)) { rem_w = it; it = 0; } else --it;
                 }
             }
         }
