@@ -288,7 +288,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel_ms": kavg_ms, "algorithmic_bytes_per_ray_step": bytes_per_step},
     }
-    if args.cpu_seconds > 0 and d is not None:
+    if args.cpu_seconds > 0 and d is not None and world == 1:      # CPU baseline: rank 0 at N = 1 only
         host = [x.cpu().numpy() for x in d]
         tc_host = tr.cpu().numpy().view(np.uint32)
         import oracle
