@@ -40,6 +40,9 @@ CONFIGS = {
     4: dict(N=512, R=2048, gen="perspective", field="f32", name="512^3 fp32 field, 2048x2048 perspective rays"),
     5: dict(N=1024, R=1024, gen="ortho", field="i16", lut=True,
             name="1024^3 uint8+LUT volume expanded to the int16 field, 1024x1024 ortho rays, opaque cores"),
+    # diagnostic variants (not BASELINE configs)
+    6: dict(N=512, R=1024, gen="ortho", field="f32", name="512^3 fp32 field, 1024x1024 orthographic rays (diagnostic)"),
+    7: dict(N=512, R=1448, gen="perspective", field="f32", name="512^3 fp32 field, 1448x1448 perspective rays (diagnostic)"),
     # small smoke-size config for quick checks
     0: dict(N=96, R=256, gen="perspective", field="f32", name="96^3 fp32 field, 256x256 perspective rays (smoke)"),
 }
