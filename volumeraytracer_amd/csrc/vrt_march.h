@@ -58,13 +58,11 @@ __device__ __forceinline__ int32_t round_to_i32(float x)
     return r;
 }
 
-// roundf(x) as uint32 two's complement for |x| < 2^30 (exact, see march_step)
-__device__ __forceinline__ uint32_t round_small_i32(float x)
+// roundf(t/2) as uint32 two's complement for |t| < 2^31, t = 2s exact (see march_step)
+__device__ __forceinline__ uint32_t round_half_i32(float t)
 {
-    const float a = __builtin_fabsf(x) + __builtin_fabsf(x);
-    const uint32_t m = ((uint32_t)a + 1u) >> 1;
-    const uint32_t sgn = (uint32_t)((int32_t)__float_as_uint(x) >> 31);   // 0 or 0xFFFFFFFF
-    return (m ^ sgn) - sgn;
+    const int32_t i = (int32_t)t;                       // v_cvt_i32_f32 truncates toward zero
+    return (uint32_t)((i + 1 + (i >> 31)) >> 1);
 }
 
 // ---- voxel pair loads: voxel z and z+1 at one (x,y), as 2 x f4 --------------------------
@@ -136,18 +134,20 @@ __device__ __forceinline__ bool march_step(Ray &r, const f4 (&c)[8], float invx,
     r.dz = fma_(g[2], invz, r.dz);
     const float dot = fma_(r.dz, r.dz, fma_(r.dx, r.dx, r.dy * r.dy));
     const float ilen = 0x42000000p0f / dot;                 // IEEE divide (.cu:346)
-    const float sx = (r.dx * invx) * ilen, sy = (r.dy * invy) * ilen, sz = (r.dz * invz) * ilen;   // .cu:347
-    if (fmaxf(fmaxf(__builtin_fabsf(sx), __builtin_fabsf(sy)), __builtin_fabsf(sz)) < 1073741824.0f) {
-        // |s| < 2^30 (always, unless the direction has collapsed): roundf by integers.  2|s| is exact,
-        // its truncation t keeps the half bit, so round-half-away(|s|) == (t + 1) >> 1; the sign is
-        // applied as two's complement.  Same value as round_to_i32 below, ten VALU ops fewer per step.
-        r.px += round_small_i32(sx);
-        r.py += round_small_i32(sy);
-        r.pz += round_small_i32(sz);
-    } else {                                                // includes NaN: x86 cvttss2si semantics
-        r.px += (uint32_t)round_to_i32(sx);
-        r.py += (uint32_t)round_to_i32(sy);
-        r.pz += (uint32_t)round_to_i32(sz);
+    // The step s = (dir*inv)*ilen (.cu:347) is needed only through roundf(s).  Doubling is exact and
+    // commutes with the rounding of the product, so t = (dir*inv)*(2*ilen) == 2s bit for bit; its
+    // truncation keeps the half bit and roundf(s) == (trunc(2s) + 1 + sign) >> 1 (arithmetic): for
+    // trunc >= 0 that is (t+1)>>1, for trunc < 0 it is floor(t/2), i.e. round half away from zero.
+    const float ilen2 = ilen + ilen;
+    const float tx = (r.dx * invx) * ilen2, ty = (r.dy * invy) * ilen2, tz = (r.dz * invz) * ilen2;
+    if (fmaxf(fmaxf(__builtin_fabsf(tx), __builtin_fabsf(ty)), __builtin_fabsf(tz)) < 2147483648.0f) {
+        r.px += round_half_i32(tx);                         // |s| < 2^30: always, unless the direction has collapsed
+        r.py += round_half_i32(ty);
+        r.pz += round_half_i32(tz);
+    } else {                                                // includes NaN / inf: x86 cvttss2si semantics
+        r.px += (uint32_t)round_to_i32(tx * 0.5f);
+        r.py += (uint32_t)round_to_i32(ty * 0.5f);
+        r.pz += (uint32_t)round_to_i32(tz * 0.5f);
     }
     return false;
 }
