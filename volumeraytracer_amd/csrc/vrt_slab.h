@@ -302,9 +302,15 @@ hipError_t launch_slab_bytes(const MarchParams &p, hipStream_t s)
 }
 
 template <typename FieldT, typename DirT>
-hipError_t launch_slab(MarchParams p, bool /*path*/, int /*num_cu*/, hipStream_t s)
+hipError_t launch_slab(MarchParams p, bool /*path*/, int num_cu, hipStream_t s)
 {
-    const uint32_t want = p.slab_lds_bytes ? p.slab_lds_bytes : 6144u;   // measured best on configs 3 and 5
+    // default: 6 KiB (26 waves/CU) measured best when the launch oversubscribes the GPU (configs 3-5); a
+    // launch with fewer wavefronts than LDS slots loses nothing to a bigger segment and gains longer rounds
+    uint32_t want = p.slab_lds_bytes;
+    if (want == 0) {
+        const uint64_t waves_per_cu = ((uint64_t)p.nrays + 63) / 64 / (uint64_t)(num_cu > 0 ? num_cu : 256);
+        want = waves_per_cu <= 20 ? 8192u : 6144u;
+    }
     if (want <= 4096) return launch_slab_bytes<FieldT, DirT, 4096, 8>(p, s);
     if (want <= 5120) return launch_slab_bytes<FieldT, DirT, 5120, 8>(p, s);
     if (want <= 6144) return launch_slab_bytes<FieldT, DirT, 6144, 6>(p, s);
