@@ -215,3 +215,39 @@ def test_config2_properties():
     # all rays of this transparent scene leave the field: physical invariant |dir| == ior at exit (ior -> 1)
     steps = b["end_iteration"].astype(np.int64)
     assert steps.min() > 100 and steps.max() < 100000
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("fdt", [np.float32, np.int16])
+def test_torture_rare_paths(fdt, kernel):
+    """Rare arithmetic paths: collapsed / tiny / huge directions (division by ~0, steps beyond 2^30 ->
+    the x86 cvttss2si INT_MIN rule), large gradients, anisotropic invscale, mixed opaque voxels."""
+    rng = np.random.RandomState(123)
+    B = [18, 22, 20]
+    n = B[0] * B[1] * B[2]
+    if fdt == np.float32:
+        d = [(rng.randn(n) * 3000).astype(np.float32) for _ in range(3)]
+    else:
+        d = [rng.randint(-20000, 20000, n).astype(np.int16) for _ in range(3)]
+    tc = np.where(rng.rand(n) < 0.97, 0xFFFFFFFF, rng.randint(0, 2 ** 31, n)).astype(np.uint32)
+    field = oracle.port.interleave(d[0], d[1], d[2], tc)
+    m = 4096
+    pv = rng.rand(m, 3) * (np.array(B) - 1.001)
+    sp = np.round(pv * 65536).astype(np.uint32).reshape(-1)
+    dirs = rng.randn(m, 3).astype(np.float32)
+    scale = np.float32(10.0) ** rng.uniform(-9, 3, m).astype(np.float32)       # 1e-9 .. 1e3
+    dirs *= scale[:, None]
+    dirs[::97] = 0.0                                                           # exactly collapsed directions
+    dirs[5::101, 1:] = 0.0
+    sd = dirs.reshape(-1)
+    with capi.Engine.from_host(B, d, tc) as eng:
+        for inv in ([1, 1, 1], [7.5, 0.25, 3.0], [1e-3, 1e3, 1.0]):
+            want = oracle.port.trace(field, B, sp, sd, inv, 3000)
+            for sort in (-1, 1):
+                got = eng.trace(sp, sd, inv, 3000, options=_opts(kernel, sort))
+                _assert_same(got, want, ctx="inv=%s sort=%d" % (inv, sort))
+        # int16 directions including zeros and extremes
+        sdi = rng.randint(-32768, 32768, 3 * m).astype(np.int16)
+        sdi[::50] = 0
+        want = oracle.port.trace(field, B, sp, sdi, [1, 2, 0.5], 3000)
+        _assert_same(eng.trace(sp, sdi, [1, 2, 0.5], 3000, options=_opts(kernel)), want, ctx="i16 dirs")
