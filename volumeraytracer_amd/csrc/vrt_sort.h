@@ -50,15 +50,15 @@ __global__ __launch_bounds__(256) void k_ray_bounds(const uint32_t *pos, uint32_
     }
 }
 
-// key layout, most significant first:
-//   work bucket:3 | dom:3 | depth bin:8 | tile u:11 | tile v (serpentine):11 | row inside tile:4 | v fine:24
-// The work bucket orders wavefronts longest-first (LPT): the straight-line distance to the field
-// boundary estimates a ray's step count, so the wavefronts dispatched last are the short ones and
-// the end of the launch does not wait on a full-length straggler.
+// 32-bit key, most significant first:
+//   work bucket:3 | dom:3 | depth bin:4 | tile u:8 | tile v (serpentine):8 | row inside tile:3 | v inside tile:3
+// (a 64-bit key with finer fields sorted no better and cost twice the radix passes: 0.6 -> 0.3 ms per
+// 10^6 rays).  The optional work bucket orders wavefronts longest-first (LPT) from the straight-line
+// distance to the field boundary; off by default (measured: -2 % on config 4, +12 % on config 3).
 template <typename DirT>
 __global__ __launch_bounds__(256) void k_tile_keys(const uint32_t *pos, const DirT *dir, uint32_t n,
                                                    const RayBounds *rb, uint32_t Bx, uint32_t By, uint32_t Bz,
-                                                   int lpt, uint64_t *keys, uint32_t *vals)
+                                                   int lpt, uint32_t *keys, uint32_t *vals)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -79,36 +79,35 @@ __global__ __launch_bounds__(256) void k_tile_keys(const uint32_t *pos, const Di
     float W = sqrtf(64.0f * ru * rv / (float)n);
     if (rw > 2.0f * W) W = cbrtf(64.0f * ru * rv * rw / (float)n);
     W = fminf(fmaxf(W, 4096.0f), 64.0f * 65536.0f);
-    W = fmaxf(W, fmaxf(ru, rv) / 2040.0f);                       // at most 2047 tiles per axis
+    W = fmaxf(W, fmaxf(ru, rv) / 254.0f);                        // at most 255 tiles per axis (bigger tiles beyond)
     const float invW = 1.0f / W;
     const float fu = (float)(p[au] - rb->lo[au]) * invW, fv = (float)(p[av] - rb->lo[av]) * invW;
     uint32_t tu = (uint32_t)fu, tv = (uint32_t)fv;
-    tu = tu > 2047u ? 2047u : tu;
-    tv = tv > 2047u ? 2047u : tv;
-    uint32_t row = (uint32_t)((fu - (float)tu) * 16.0f);
-    row = row > 15u ? 15u : row;
-    uint32_t wb = (uint32_t)((float)(p[aw] - rb->lo[aw]) * fminf(invW, 255.0f / rw));
-    wb = wb > 255u ? 255u : wb;
-    uint32_t vf = (p[av] - rb->lo[av]) >> 8;
-    vf = vf > 0xFFFFFFu ? 0xFFFFFFu : vf;
-    if (tu & 1u) { tv = 2047u - tv; vf = 0xFFFFFFu - vf; }       // serpentine: odd tile columns run backwards
-    // straight-line exit distance (voxels) inside [0, B-1]^3, relative to the longest axis
-    const float d3[3] = {dx, dy, dz};
-    const float hi3[3] = {(float)(Bx - 1) * 65536.0f, (float)(By - 1) * 65536.0f, (float)(Bz - 1) * 65536.0f};
-    float t = 3.0e38f;
+    tu = tu > 255u ? 255u : tu;
+    tv = tv > 255u ? 255u : tv;
+    uint32_t row = (uint32_t)((fu - (float)tu) * 8.0f), col = (uint32_t)((fv - (float)tv) * 8.0f);
+    row = row > 7u ? 7u : row;
+    col = col > 7u ? 7u : col;
+    uint32_t wb = (uint32_t)((float)(p[aw] - rb->lo[aw]) * fminf(invW, 15.0f / rw));
+    wb = wb > 15u ? 15u : wb;
+    if (tu & 1u) { tv = 255u - tv; col = 7u - col; }             // serpentine: odd tile columns run backwards
+    uint32_t bucket = 7u;
+    if (lpt) {
+        // straight-line exit distance inside [0, B-1]^3, relative to the longest axis
+        const float d3[3] = {dx, dy, dz};
+        const float hi3[3] = {(float)(Bx - 1) * 65536.0f, (float)(By - 1) * 65536.0f, (float)(Bz - 1) * 65536.0f};
+        float t = 3.0e38f;
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        const float pd = (float)p[d];
-        if (d3[d] > 0.0f) t = fminf(t, (hi3[d] - pd) / d3[d]);
-        else if (d3[d] < 0.0f) t = fminf(t, -pd / d3[d]);
+        for (int d = 0; d < 3; ++d) {
+            const float pd = (float)p[d];
+            if (d3[d] > 0.0f) t = fminf(t, (hi3[d] - pd) / d3[d]);
+            else if (d3[d] < 0.0f) t = fminf(t, -pd / d3[d]);
+        }
+        const float len = t < 3.0e38f ? t * sqrtf(dx * dx + dy * dy + dz * dz) : 0.0f;
+        const int b = (int)(len * 6.0f / fmaxf(fmaxf(hi3[0], hi3[1]), hi3[2]));
+        bucket = (uint32_t)(b < 0 ? 0 : (b > 7 ? 7 : b));
     }
-    const float len = t < 3.0e38f ? t * sqrtf(dx * dx + dy * dy + dz * dz) : 0.0f;
-    const float ref = fmaxf(fmaxf(hi3[0], hi3[1]), hi3[2]);
-    int bucket = (int)(len * 6.0f / ref);                        // 0 (short) .. 7 (longer than the longest axis)
-    bucket = bucket < 0 ? 0 : (bucket > 7 ? 7 : bucket);
-    if (!lpt) bucket = 7;
-    keys[i] = ((uint64_t)(7 - bucket) << 61) | ((uint64_t)dom << 58) | ((uint64_t)wb << 50) | ((uint64_t)tu << 39) |
-              ((uint64_t)tv << 28) | ((uint64_t)row << 24) | (uint64_t)vf;
+    keys[i] = ((7u - bucket) << 29) | (dom << 26) | (wb << 22) | (tu << 14) | (tv << 6) | (row << 3) | col;
     vals[i] = i;
 }
 
@@ -120,8 +119,8 @@ hipError_t build_tile_order(const uint32_t *d_pos, const void *d_dir, int dir_is
                             const uint32_t **order_out)
 {
     hipError_t e;
-    if ((e = keys.reserve((size_t)n * 8)) != hipSuccess) return e;
-    if ((e = keys_alt.reserve((size_t)n * 8)) != hipSuccess) return e;
+    if ((e = keys.reserve((size_t)n * 4)) != hipSuccess) return e;
+    if ((e = keys_alt.reserve((size_t)n * 4)) != hipSuccess) return e;
     if ((e = vals.reserve((size_t)n * 4)) != hipSuccess) return e;
     if ((e = vals_alt.reserve((size_t)n * 4)) != hipSuccess) return e;
     if ((e = bounds.reserve(sizeof(RayBounds))) != hipSuccess) return e;
@@ -130,16 +129,16 @@ hipError_t build_tile_order(const uint32_t *d_pos, const void *d_dir, int dir_is
     const unsigned rgrid = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
     k_ray_bounds<<<rgrid, 256, 0, s>>>(d_pos, n, rb);
     const unsigned grid = (n + 255) / 256;
-    if (dir_is_i16) k_tile_keys<int16_t><<<grid, 256, 0, s>>>(d_pos, (const int16_t *)d_dir, n, rb, Bx, By, Bz, lpt, (uint64_t *)keys.p, (uint32_t *)vals.p);
-    else            k_tile_keys<float><<<grid, 256, 0, s>>>(d_pos, (const float *)d_dir, n, rb, Bx, By, Bz, lpt, (uint64_t *)keys.p, (uint32_t *)vals.p);
+    if (dir_is_i16) k_tile_keys<int16_t><<<grid, 256, 0, s>>>(d_pos, (const int16_t *)d_dir, n, rb, Bx, By, Bz, lpt, (uint32_t *)keys.p, (uint32_t *)vals.p);
+    else            k_tile_keys<float><<<grid, 256, 0, s>>>(d_pos, (const float *)d_dir, n, rb, Bx, By, Bz, lpt, (uint32_t *)keys.p, (uint32_t *)vals.p);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     size_t tmp_bytes = 0;
-    e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const uint64_t *)keys.p, (uint64_t *)keys_alt.p,
-                                  (const uint32_t *)vals.p, (uint32_t *)vals_alt.p, n, 0, 64, s);
+    e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const uint32_t *)keys.p, (uint32_t *)keys_alt.p,
+                                  (const uint32_t *)vals.p, (uint32_t *)vals_alt.p, n, 0, 32, s);
     if (e != hipSuccess) return e;
     if ((e = tmp.reserve(tmp_bytes ? tmp_bytes : 16)) != hipSuccess) return e;
-    e = rocprim::radix_sort_pairs(tmp.p, tmp_bytes, (const uint64_t *)keys.p, (uint64_t *)keys_alt.p,
-                                  (const uint32_t *)vals.p, (uint32_t *)vals_alt.p, n, 0, 64, s);
+    e = rocprim::radix_sort_pairs(tmp.p, tmp_bytes, (const uint32_t *)keys.p, (uint32_t *)keys_alt.p,
+                                  (const uint32_t *)vals.p, (uint32_t *)vals_alt.p, n, 0, lpt ? 32 : 29, s);
     if (e != hipSuccess) return e;
     *order_out = (const uint32_t *)vals_alt.p;
     return hipSuccess;
