@@ -59,7 +59,13 @@ typedef struct vrt_options {
     int32_t  kernel;         /* extension: VRT_KERNEL_* selector, 0 = auto */
     int32_t  sort_rays;      /* extension: 0 = auto, 1 = tile ordering, 2 = tile ordering longest-first, -1 = keep caller order */
     int32_t  slab_lds_bytes; /* extension: LDS bytes per wavefront for the slab kernel, 0 = default */
-    int32_t  reserved[4];
+    int32_t  absorption;     /* extension, opt-in: 1 = run the absorption branch the reference compiles out
+                              * (cuda_volume_raytracer.cu:337-341): per step brightness -= min(brightness,
+                              * 0xFFFFFFFF - translucency[voxel]); stop when brightness < min_brightness;
+                              * remaining_light returns the brightness.  Must be set at vrt_create (keeps the
+                              * translucency resident) AND at vrt_trace.  PARITY UNPINNED: no reference build
+                              * can execute this branch; the checker is oracle/vrt_oracle.c's restatement. */
+    int32_t  reserved[3];
 } vrt_options;
 
 #define VRT_KERNEL_AUTO   0

@@ -91,8 +91,11 @@ class _Port:
            _c.c_size_t(n), _ptr(out))
         return out
 
-    def trace(self, field, bounds, start_pos, start_dir, invscale, iterations, trace_paths=False, nthreads=0):
-        """Seam-level trace on an interleaved field.  Returns dict of outputs."""
+    def trace(self, field, bounds, start_pos, start_dir, invscale, iterations, trace_paths=False, nthreads=0,
+              absorb_translucency=None, min_brightness=0):
+        """Seam-level trace on an interleaved field.  Returns dict of outputs.
+        absorb_translucency (uint32 per field voxel) switches on the opt-in absorption mode
+        (the reference's dead branch cuda_volume_raytracer.cu:337-341; parity unpinned)."""
         field = np.ascontiguousarray(field)
         ft = VRT_F32 if field.dtype == np.float32 else VRT_I16
         start_dir = np.ascontiguousarray(start_dir)
@@ -106,9 +109,16 @@ class _Port:
         ei = np.empty(n, np.uint32)
         rl = np.empty(n, np.uint32)
         path = np.empty(int(iterations) * 3 * n, np.uint32) if trace_paths else None
-        rc = self.lib().vrt_oracle_trace(ft, dtp, _ptr(field), _ptr(b), _ptr(inv), _c.c_size_t(n), _ptr(sp),
-                                         _ptr(start_dir.reshape(-1)), _ptr(ep), _ptr(ed), _ptr(ei), _ptr(rl),
-                                         _ptr(path), _c.c_uint32(int(iterations)), int(nthreads))
+        if absorb_translucency is None:
+            rc = self.lib().vrt_oracle_trace(ft, dtp, _ptr(field), _ptr(b), _ptr(inv), _c.c_size_t(n), _ptr(sp),
+                                             _ptr(start_dir.reshape(-1)), _ptr(ep), _ptr(ed), _ptr(ei), _ptr(rl),
+                                             _ptr(path), _c.c_uint32(int(iterations)), int(nthreads))
+        else:
+            tr = _as(absorb_translucency, np.uint32).reshape(-1)
+            rc = self.lib().vrt_oracle_trace_absorb(ft, dtp, _ptr(field), _ptr(b), _ptr(inv), _c.c_size_t(n), _ptr(sp),
+                                                    _ptr(start_dir.reshape(-1)), _ptr(ep), _ptr(ed), _ptr(ei), _ptr(rl),
+                                                    _ptr(path), _c.c_uint32(int(iterations)), int(nthreads), _ptr(tr),
+                                                    _c.c_uint32(int(min_brightness)))
         if rc != 0:
             raise RuntimeError("vrt_oracle_trace failed: %d" % rc)
         return dict(end_position=ep, end_direction=ed, end_iteration=ei, remaining_light=rl, path=path)

@@ -113,19 +113,29 @@ typedef struct {
     uint32_t remaining;  /* raydata._iterations on return */
 } ray_state;
 
+/* transl == NULL reproduces every reference call site (translucency is a DummyArray, .cu:882-938).
+ * transl != NULL is the OPT-IN absorption mode: the branch at .cu:337-341 that the reference compiles
+ * out.  PARITY UNPINNED for that mode -- the reference cannot execute it; this is its restatement. */
 static void trace_one(int field_type, const void *field, const uint16_t bounds[3], const float inv[3],
-                      ray_state *r, uint32_t iterations, uint32_t *path /* iterations*3 or NULL */)
+                      ray_state *r, uint32_t iterations, uint32_t *path /* iterations*3 or NULL */,
+                      const uint32_t *transl, uint32_t min_brightness, uint32_t *brightness_out)
 {
     const uint32_t By = bounds[1], Bz = bounds[2];
     const uint16_t bx1 = (uint16_t)(bounds[0] - 1), by1 = (uint16_t)(bounds[1] - 1), bz1 = (uint16_t)(bounds[2] - 1);
     uint32_t px = r->pos[0], py = r->pos[1], pz = r->pos[2];
     float dx = r->dir[0], dy = r->dir[1], dz = r->dir[2];
     uint32_t it = iterations;
+    uint32_t brightness = 0xFFFFFFFFu;                        /* .cu:332 */
     --it;                                                     /* .cu:333 path[--iterations] = pos */
     if (path) { path[3 * (size_t)it] = px; path[3 * (size_t)it + 1] = py; path[3 * (size_t)it + 2] = pz; }
     /* .cu:335 -- "iterations-- > 0 && all(uint16(pos>>16) < uint16(bounds-1))" */
     while (it-- > 0 && (uint16_t)(px >> 16) < bx1 && (uint16_t)(py >> 16) < by1 && (uint16_t)(pz >> 16) < bz1) {
         size_t idx = ((size_t)((px >> 16) * By + (py >> 16))) * Bz + (pz >> 16);   /* .cu:113 */
+        if (transl) {                                          /* .cu:337-341 */
+            uint32_t dec = 0xFFFFFFFFu - transl[idx];
+            brightness -= brightness < dec ? brightness : dec;
+            if (brightness < min_brightness) break;
+        }
         float v0[8], v1[8], v2[8], v3[8], g[4];
         if (field_type == VRT_F32) {
             const float *f = (const float *)field + 4 * idx;
@@ -159,6 +169,7 @@ static void trace_one(int field_type, const void *field, const uint16_t bounds[3
     }
     r->pos[0] = px; r->pos[1] = py; r->pos[2] = pz;
     r->dir[0] = dx; r->dir[1] = dy; r->dir[2] = dz;
+    *brightness_out = brightness;                             /* .cu:370-373 (0xFFFFFFFF when transl == NULL, .cu:485) */
 }
 
 /*
@@ -169,11 +180,12 @@ static void trace_one(int field_type, const void *field, const uint16_t bounds[3
  * Positions are in field coordinates (already shifted by the caller).
  * path: NULL or iterations*3*nrays uint32.  Returns 0, or -1 on bad arguments.
  */
-int vrt_oracle_trace(int field_type, int dir_type, const void *field, const uint16_t bounds[3],
-                     const float invscale[3], size_t nrays,
-                     const uint32_t *start_pos, const void *start_dir,
-                     uint32_t *end_pos, void *end_dir, uint32_t *end_iter, uint32_t *remaining_light,
-                     uint32_t *path, uint32_t iterations, int nthreads)
+static int trace_impl(int field_type, int dir_type, const void *field, const uint16_t bounds[3],
+                      const float invscale[3], size_t nrays,
+                      const uint32_t *start_pos, const void *start_dir,
+                      uint32_t *end_pos, void *end_dir, uint32_t *end_iter, uint32_t *remaining_light,
+                      uint32_t *path, uint32_t iterations, int nthreads,
+                      const uint32_t *transl, uint32_t min_brightness)
 {
     if (iterations == 0) return -1;
     if (field_type != VRT_F32 && field_type != VRT_I16) return -1;
@@ -194,8 +206,9 @@ int vrt_oracle_trace(int field_type, int dir_type, const void *field, const uint
             const int16_t *d = (const int16_t *)start_dir + 3 * i;
             for (int k = 0; k < 3; ++k) r.dir[k] = (float)d[k] * 256.0f;
         }
+        uint32_t bright;
         trace_one(field_type, field, bounds, invscale, &r, iterations,
-                  path ? path + (size_t)iterations * 3 * i : NULL);
+                  path ? path + (size_t)iterations * 3 * i : NULL, transl, min_brightness, &bright);
         end_pos[3 * i] = r.pos[0]; end_pos[3 * i + 1] = r.pos[1]; end_pos[3 * i + 2] = r.pos[2];
         if (dir_type == VRT_F32) {                            /* .cu:364-367 */
             float *d = (float *)end_dir + 3 * i;
@@ -205,9 +218,32 @@ int vrt_oracle_trace(int field_type, int dir_type, const void *field, const uint
             for (int k = 0; k < 3; ++k) d[k] = (int16_t)float2int_round(r.dir[k] * (1.0f / 256.0f));
         }
         end_iter[i] = iterations - r.remaining;               /* .cu:953-956 */
-        remaining_light[i] = 0xFFFFFFFFu;                     /* .cu:485 */
+        remaining_light[i] = bright;                          /* .cu:485 / .cu:370-373 */
     }
     return 0;
+}
+
+int vrt_oracle_trace(int field_type, int dir_type, const void *field, const uint16_t bounds[3],
+                     const float invscale[3], size_t nrays,
+                     const uint32_t *start_pos, const void *start_dir,
+                     uint32_t *end_pos, void *end_dir, uint32_t *end_iter, uint32_t *remaining_light,
+                     uint32_t *path, uint32_t iterations, int nthreads)
+{
+    return trace_impl(field_type, dir_type, field, bounds, invscale, nrays, start_pos, start_dir, end_pos, end_dir,
+                      end_iter, remaining_light, path, iterations, nthreads, NULL, 0);
+}
+
+/* Opt-in absorption mode (PARITY UNPINNED, see trace_one): transl_cropped has one uint32 per field voxel. */
+int vrt_oracle_trace_absorb(int field_type, int dir_type, const void *field, const uint16_t bounds[3],
+                            const float invscale[3], size_t nrays,
+                            const uint32_t *start_pos, const void *start_dir,
+                            uint32_t *end_pos, void *end_dir, uint32_t *end_iter, uint32_t *remaining_light,
+                            uint32_t *path, uint32_t iterations, int nthreads,
+                            const uint32_t *transl_cropped, uint32_t min_brightness)
+{
+    if (!transl_cropped) return -1;
+    return trace_impl(field_type, dir_type, field, bounds, invscale, nrays, start_pos, start_dir, end_pos, end_dir,
+                      end_iter, remaining_light, path, iterations, nthreads, transl_cropped, min_brightness);
 }
 
 /* ========================================================================== *

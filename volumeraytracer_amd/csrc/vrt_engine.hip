@@ -92,6 +92,7 @@ struct vrt_engine {
     int num_cu = 256;
     // workspaces (grow-only; no allocation in steady state)
     DevBuf sort_keys, sort_keys_alt, sort_vals, sort_vals_alt, sort_tmp, sort_bounds;
+    DevBuf transl;                 // translucency per field voxel, kept only for the opt-in absorption mode
     DevBuf stats;                  // debug counters, allocated only when VRT_DEBUG_STATS=1
     DevBuf h_in_pos, h_in_dir, h_out_pos, h_out_dir, h_out_iter, h_out_light, h_path;
     vrt_options opt;
@@ -207,7 +208,7 @@ void engine_free(vrt_engine *e)
     if (e->field) (void)hipFree(e->field);
     if (e->ev_begin) (void)hipEventDestroy(e->ev_begin);
     if (e->ev_end) (void)hipEventDestroy(e->ev_end);
-    DevBuf *bufs[] = {&e->stats, &e->sort_keys, &e->sort_keys_alt, &e->sort_vals, &e->sort_vals_alt, &e->sort_tmp, &e->sort_bounds,
+    DevBuf *bufs[] = {&e->transl, &e->stats, &e->sort_keys, &e->sort_keys_alt, &e->sort_vals, &e->sort_vals_alt, &e->sort_tmp, &e->sort_bounds,
                       &e->h_in_pos, &e->h_in_dir, &e->h_out_pos, &e->h_out_dir, &e->h_out_iter, &e->h_out_light,
                       &e->h_path};
     for (DevBuf *b : bufs) b->release();
@@ -225,8 +226,13 @@ int launch_typed(vrt_engine *e, const vrt::MarchParams &p, int kernel, hipStream
                    ? VRT_OK : fail(VRT_ERR_HIP, "slab kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     }
     const unsigned grid = (p.nrays + 255) / 256;
-    if (path) vrt::k_march_direct<FieldT, DirT, true><<<grid, 256, 0, s>>>(p);
-    else      vrt::k_march_direct<FieldT, DirT, false><<<grid, 256, 0, s>>>(p);
+    if (p.transl) {
+        if (path) vrt::k_march_direct<FieldT, DirT, true, true><<<grid, 256, 0, s>>>(p);
+        else      vrt::k_march_direct<FieldT, DirT, false, true><<<grid, 256, 0, s>>>(p);
+    } else {
+        if (path) vrt::k_march_direct<FieldT, DirT, true, false><<<grid, 256, 0, s>>>(p);
+        else      vrt::k_march_direct<FieldT, DirT, false, false><<<grid, 256, 0, s>>>(p);
+    }
     HIP_TRY(hipGetLastError());
     return VRT_OK;
 }
@@ -234,7 +240,7 @@ int launch_typed(vrt_engine *e, const vrt::MarchParams &p, int kernel, hipStream
 int trace_device_impl(vrt_engine *e, int dir_type, size_t nrays, const uint32_t *d_sp, const void *d_sd,
                       uint32_t *d_ep, void *d_ed, uint32_t *d_ei, uint32_t *d_rl, uint32_t *d_path,
                       const float *invscale, uint32_t iterations, hipStream_t s, const vrt_options *opt,
-                      uint32_t out_pos_bias = 0)
+                      uint32_t out_pos_bias = 0, uint32_t min_brightness = 0)
 {
     if (nrays == 0) return VRT_OK;
     const vrt_options &o = opt ? *opt : e->opt;
@@ -249,6 +255,14 @@ int trace_device_impl(vrt_engine *e, int dir_type, size_t nrays, const uint32_t 
     p.iterations = iterations;
     p.nrays = (uint32_t)nrays;
     p.out_pos_bias = out_pos_bias;
+    p.transl = nullptr;
+    p.min_brightness = min_brightness;
+    if (o.absorption) {
+        if (!e->transl.p)
+            return fail(VRT_ERR_INVALID_ARGUMENT, "absorption requested at trace time but the engine was created "
+                                                  "without vrt_options.absorption = 1 (translucency not resident)");
+        p.transl = (const uint32_t *)e->transl.p;
+    }
     p.slab_lds_bytes = 0;
     if (o.slab_lds_bytes > 0) {
         if (o.slab_lds_bytes < 1024 || o.slab_lds_bytes > 40960 || (o.slab_lds_bytes & 15))
@@ -312,7 +326,7 @@ int check_trace_args(vrt_handle h, int dir_type, size_t nrays, const void *sp, c
 template <typename Pre>
 int trace_host_impl(vrt_engine *e, int dir_type, size_t nrays, const uint32_t *sp, const void *sd, uint32_t *ep,
                     void *ed, uint32_t *ei, uint32_t *rl, uint32_t *path, const float *invscale, uint32_t iterations,
-                    const vrt_options *opt, uint32_t out_pos_bias, Pre pre)
+                    const vrt_options *opt, uint32_t out_pos_bias, uint32_t min_brightness, Pre pre)
 {
     const vrt_options &o = opt ? *opt : e->opt;
     const size_t dsz = dir_type == VRT_F32 ? 4 : 2;
@@ -346,7 +360,7 @@ int trace_host_impl(vrt_engine *e, int dir_type, size_t nrays, const uint32_t *s
         rc = trace_device_impl(e, dir_type, n, (const uint32_t *)e->h_in_pos.p, e->h_in_dir.p,
                                (uint32_t *)e->h_out_pos.p, e->h_out_dir.p, (uint32_t *)e->h_out_iter.p,
                                (uint32_t *)e->h_out_light.p, path ? (uint32_t *)e->h_path.p : nullptr, invscale,
-                               iterations, s, opt, out_pos_bias);
+                               iterations, s, opt, out_pos_bias, min_brightness);
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(ep + 3 * off, e->h_out_pos.p, n * 12, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync((char *)ed + 3 * off * dsz, e->h_out_dir.p, n * 3 * dsz, hipMemcpyDeviceToHost, s));
@@ -432,6 +446,11 @@ int vrt_create_from_device(vrt_handle *out, int dim, const uint16_t *bounds, int
     if (rc) return rc;
     DeviceGuard g(e->device);
     rc = engine_init_device(e);
+    if (!rc && e->opt.absorption) {
+        if (e->transl.reserve(nvox * 4) != hipSuccess) rc = fail(VRT_ERR_OUT_OF_MEMORY, "device allocation failed");
+        else if (hipMemcpyAsync(e->transl.p, d_tr, nvox * 4, hipMemcpyDeviceToDevice, e->stream) != hipSuccess)
+            rc = fail(VRT_ERR_HIP, "translucency copy failed");
+    }
     if (!rc) rc = launch_interleave(e, d_diff, d_tr, 0, nvox, e->stream);
     if (!rc && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail(VRT_ERR_HIP, "field interleave failed");
     if (rc) { engine_free(e); return rc; }
@@ -461,8 +480,13 @@ int vrt_create(vrt_handle *out, int dim, const uint16_t *bounds, int field_type,
     for (int k = 0; k < 3; ++k)
         if (tmp[k].reserve(chunk * esz) != hipSuccess) return cleanup(fail(VRT_ERR_OUT_OF_MEMORY, "device allocation failed"));
     if (tmp[3].reserve(chunk * 4) != hipSuccess) return cleanup(fail(VRT_ERR_OUT_OF_MEMORY, "device allocation failed"));
+    if (e->opt.absorption && e->transl.reserve(nvox * 4) != hipSuccess)
+        return cleanup(fail(VRT_ERR_OUT_OF_MEMORY, "device allocation failed"));
     for (size_t off = 0; off < nvox; off += chunk) {
         const size_t n = std::min(chunk, nvox - off);
+        if (e->opt.absorption &&
+            hipMemcpyAsync((uint32_t *)e->transl.p + off, tr + off, n * 4, hipMemcpyHostToDevice, e->stream) != hipSuccess)
+            return cleanup(fail(VRT_ERR_HIP, "field upload failed"));
         for (int k = 0; k < 3; ++k)
             if (hipMemcpyAsync(tmp[k].p, (const char *)diff[k] + off * esz, n * esz, hipMemcpyHostToDevice, e->stream) != hipSuccess)
                 return cleanup(fail(VRT_ERR_HIP, "field upload failed"));
@@ -480,25 +504,26 @@ int vrt_create(vrt_handle *out, int dim, const uint16_t *bounds, int field_type,
 
 int vrt_trace_device(vrt_handle h, int dir_type, size_t nrays, const uint32_t *d_sp, const void *d_sd,
                      uint32_t *d_ep, void *d_ed, uint32_t *d_ei, uint32_t *d_rl, uint32_t *d_path,
-                     const float *invscale, uint32_t /*min_brightness*/, uint32_t iterations, void *stream,
+                     const float *invscale, uint32_t min_brightness, uint32_t iterations, void *stream,
                      const vrt_options *opt)
 {
     int rc = check_trace_args(h, dir_type, nrays, d_sp, d_sd, d_ep, d_ed, d_ei, d_rl, invscale, iterations);
     if (rc) return rc;
     DeviceGuard g(h->device);
+    // min_brightness is ignored unless the opt-in absorption mode is on, as in the reference (.cu:785)
     return trace_device_impl(h, dir_type, nrays, d_sp, d_sd, d_ep, d_ed, d_ei, d_rl, d_path, invscale, iterations,
-                             (hipStream_t)stream, opt);
+                             (hipStream_t)stream, opt, 0, min_brightness);
 }
 
 int vrt_trace(vrt_handle h, int dir_type, size_t nrays, const uint32_t *sp, const void *sd, uint32_t *ep, void *ed,
-              uint32_t *ei, uint32_t *rl, uint32_t *path, const float *invscale, uint32_t /*min_brightness*/,
+              uint32_t *ei, uint32_t *rl, uint32_t *path, const float *invscale, uint32_t min_brightness,
               uint32_t iterations, const vrt_options *opt)
 {
     int rc = check_trace_args(h, dir_type, nrays, sp, sd, ep, ed, ei, rl, invscale, iterations);
     if (rc) return rc;
     if (nrays == 0) return VRT_OK;
     DeviceGuard g(h->device);
-    return trace_host_impl(h, dir_type, nrays, sp, sd, ep, ed, ei, rl, path, invscale, iterations, opt, 0,
+    return trace_host_impl(h, dir_type, nrays, sp, sd, ep, ed, ei, rl, path, invscale, iterations, opt, 0, min_brightness,
                            [](uint32_t *, void *, size_t, size_t, hipStream_t) { return (int)VRT_OK; });
 }
 
@@ -594,23 +619,28 @@ static int scene_create_impl(vrt_scene_handle *out, int dim, const size_t *bound
         hipMemcpyAsync(d_tr, translucency, ntab * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
         hipMemsetAsync(sc->d_err, 0, sizeof(vrt::SceneErr), s) != hipSuccess)
         return cleanup(fail(VRT_ERR_HIP, "scene upload failed"));
+    uint32_t *d_tc = nullptr;
+    if (e->opt.absorption) {
+        if (e->transl.reserve(fvox * 4) != hipSuccess) return cleanup(fail(VRT_ERR_OUT_OF_MEMORY, "device allocation failed"));
+        d_tc = (uint32_t *)e->transl.p;
+    }
     const unsigned grid = (unsigned)((fvox + 255) / 256);
     vrt::SceneErr *derr = (vrt::SceneErr *)sc->d_err;
     const uint8_t *dd = (const uint8_t *)sc->d_density;
     if (ior_type == VRT_F32) {
         if (density)
             vrt::k_scene_build<<<grid, 256, 0, s>>>(vrt::SrcLut<float>{dd, (const float *)d_lg}, vrt::SrcLut<uint32_t>{dd, (const uint32_t *)d_tr},
-                                                    sc->N[0], sc->N[1], sc->N[2], (vrt::vox_f32 *)e->field, derr);
+                                                    sc->N[0], sc->N[1], sc->N[2], (vrt::vox_f32 *)e->field, derr, d_tc);
         else
             vrt::k_scene_build<<<grid, 256, 0, s>>>(vrt::SrcArray<float>{(const float *)d_lg}, vrt::SrcArray<uint32_t>{(const uint32_t *)d_tr},
-                                                    sc->N[0], sc->N[1], sc->N[2], (vrt::vox_f32 *)e->field, derr);
+                                                    sc->N[0], sc->N[1], sc->N[2], (vrt::vox_f32 *)e->field, derr, d_tc);
     } else {
         if (density)
             vrt::k_scene_build<<<grid, 256, 0, s>>>(vrt::SrcLut<int32_t>{dd, (const int32_t *)d_lg}, vrt::SrcLut<uint32_t>{dd, (const uint32_t *)d_tr},
-                                                    sc->N[0], sc->N[1], sc->N[2], (vrt::vox_i16 *)e->field, derr);
+                                                    sc->N[0], sc->N[1], sc->N[2], (vrt::vox_i16 *)e->field, derr, d_tc);
         else
             vrt::k_scene_build<<<grid, 256, 0, s>>>(vrt::SrcArray<int32_t>{(const int32_t *)d_lg}, vrt::SrcArray<uint32_t>{(const uint32_t *)d_tr},
-                                                    sc->N[0], sc->N[1], sc->N[2], (vrt::vox_i16 *)e->field, derr);
+                                                    sc->N[0], sc->N[1], sc->N[2], (vrt::vox_i16 *)e->field, derr, d_tc);
     }
     if (hipGetLastError() != hipSuccess) return cleanup(fail(VRT_ERR_HIP, "scene build launch failed"));
     vrt::SceneErr herr;
@@ -640,7 +670,7 @@ int vrt_scene_create_lut(vrt_scene_handle *out, int dim, const size_t *bounds, i
 
 int vrt_scene_trace(vrt_scene_handle sc, int dir_type, size_t nrays, const uint32_t *sp, const void *sd, uint32_t *ep,
                     void *ed, uint32_t *ei, uint32_t *rl, uint32_t *path, const float *invscale,
-                    uint32_t /*min_brightness*/, uint32_t iterations, int /*normalize_length: "|| true", image_util.cpp:668*/,
+                    uint32_t min_brightness, uint32_t iterations, int /*normalize_length: "|| true", image_util.cpp:668*/,
                     const vrt_options *opt)
 {
     if (!sc) return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_scene_trace: NULL scene");
@@ -688,7 +718,7 @@ int vrt_scene_trace(vrt_scene_handle sc, int dir_type, size_t nrays, const uint3
             return fail(VRT_ERR_SCENE, "Normalize length failed: -32768<=tmp<=32767");
         return VRT_OK;
     };
-    return trace_host_impl(e, dir_type, nrays, sp, sd, ep, ed, ei, rl, path, invscale, iterations, opt, 0x10000u, pre);
+    return trace_host_impl(e, dir_type, nrays, sp, sd, ep, ed, ei, rl, path, invscale, iterations, opt, 0x10000u, min_brightness, pre);
 }
 
 void vrt_scene_destroy(vrt_scene_handle sc)

@@ -34,6 +34,8 @@ struct MarchParams {
     uint32_t nrays;
     uint32_t slab_lds_bytes;  // slab kernel: LDS bytes per wave
     unsigned long long *stats; // optional debug counters (nullptr in production), see vrt_slab.h
+    const uint32_t *transl;   // ABSORB kernels only: translucency per field voxel (opt-in mode, .cu:337-341)
+    uint32_t min_brightness;  // ABSORB kernels only
     uint32_t out_pos_bias;    // added to end_pos / path on output: 0 at the seam, 0x10000 for the scene
                               // layer's "+0x10000" epilogue (image_util.cpp:770-771)
 };
@@ -173,8 +175,19 @@ __device__ __forceinline__ void load_ray(const MarchParams &p, uint32_t ray, Ray
     }
 }
 
+// Opt-in absorption (the reference's compiled-out branch, .cu:337-341), evaluated at the ray's cell
+// before the gather.  Returns true when the ray falls below the brightness cut-off.
+__device__ __forceinline__ bool absorb_step(const MarchParams &p, const Ray &r, uint32_t &brightness)
+{
+    const size_t idx = ((size_t)((r.px >> 16) * p.By + (r.py >> 16))) * p.Bz + (r.pz >> 16);   // get_index, .cu:113
+    const uint32_t dec = 0xFFFFFFFFu - p.transl[idx];
+    brightness -= brightness < dec ? brightness : dec;
+    return brightness < p.min_brightness;
+}
+
 template <typename DirT>
-__device__ __forceinline__ void store_ray(const MarchParams &p, uint32_t ray, const Ray &r, uint32_t remaining)
+__device__ __forceinline__ void store_ray(const MarchParams &p, uint32_t ray, const Ray &r, uint32_t remaining,
+                                          uint32_t light = 0xFFFFFFFFu)
 {
     uint32_t *ep = p.end_pos + 3 * (size_t)ray;
     ep[0] = r.px + p.out_pos_bias; ep[1] = r.py + p.out_pos_bias; ep[2] = r.pz + p.out_pos_bias;
@@ -187,7 +200,7 @@ __device__ __forceinline__ void store_ray(const MarchParams &p, uint32_t ray, co
         ed[2] = (int16_t)round_to_i32(r.dz * (1.0f / 256.0f));
     }
     p.end_iter[ray] = p.iterations - remaining;
-    p.remaining_light[ray] = 0xFFFFFFFFu;
+    p.remaining_light[ray] = light;
 }
 
 __device__ __forceinline__ void path_put(uint32_t *pb, uint32_t it, const Ray &r, uint32_t bias)
@@ -217,7 +230,7 @@ __device__ __forceinline__ void gather_global(const typename FieldTraits<FieldT>
     for (int k = 0; k < 8; ++k) cvt_vox(v[k], c[k]);
 }
 
-template <typename FieldT, typename DirT, bool PATH>
+template <typename FieldT, typename DirT, bool PATH, bool ABSORB>
 __global__ __launch_bounds__(256) void k_march_direct(const MarchParams p)
 {
     using vox = typename FieldTraits<FieldT>::vox;
@@ -232,7 +245,9 @@ __global__ __launch_bounds__(256) void k_march_direct(const MarchParams p)
 
     uint32_t it = p.iterations - 1;                     // .cu:333
     if (PATH) path_put(pb, it, r, p.out_pos_bias);
+    uint32_t light = 0xFFFFFFFFu;                       // .cu:332
     while (it-- > 0 && in_field(r, bx1, by1, bz1)) {    // .cu:335
+        if constexpr (ABSORB) { if (absorb_step(p, r, light)) break; }   // .cu:337-341
         f4 c[8];
         gather_global<FieldT>(f, r, p.By, p.Bz, c);
         if (march_step(r, c, p.invx, p.invy, p.invz)) break;
@@ -241,7 +256,7 @@ __global__ __launch_bounds__(256) void k_march_direct(const MarchParams p)
     ++it;                                               // .cu:350
     const uint32_t remaining = it;
     if (PATH) { while (it-- > 0) path_put(pb, it, r, p.out_pos_bias); } // .cu:352-358
-    store_ray<DirT>(p, ray, r, remaining);
+    store_ray<DirT>(p, ray, r, remaining, light);
 }
 
 }  // namespace vrt

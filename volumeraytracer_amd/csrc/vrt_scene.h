@@ -50,7 +50,7 @@ struct SceneErr {            // device -> host error words
 template <typename LogSrc, typename TrSrc, typename VoxT>
 __global__ __launch_bounds__(256) void k_scene_build(const LogSrc lg, const TrSrc transl,
                                                      uint32_t Nx, uint32_t Ny, uint32_t Nz, VoxT *__restrict__ field,
-                                                     SceneErr *err)
+                                                     SceneErr *err, uint32_t *__restrict__ transl_cropped /* or nullptr */)
 {
     const uint32_t Ox = Nx - 2, Oy = Ny - 2, Oz = Nz - 2;
     const size_t n = (size_t)Ox * Oy * Oz;
@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void k_scene_build(const LogSrc lg, const TrSr
         o.x = sum[0] / weight; o.y = sum[1] / weight; o.z = sum[2] / weight;              // "sum /= weight", :283-285
         o.w = (float)((int32_t)(0x7FFFFFFFu - tr) / 0x10000);                             // cuda_volume_raytracer.cu:656-659
         field[idx] = o;
+        if (transl_cropped) transl_cropped[idx] = tr;
     } else {                                              // integer family: RaytraceScene<ior_t,iorlog_t,diff_t>
         uint32_t sum[3] = {0u, 0u, 0u};                   // int32 arithmetic wraps in the reference binary
 #pragma unroll
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(256) void k_scene_build(const LogSrc lg, const TrSr
         v.x = o[0]; v.y = o[1]; v.z = o[2];
         v.w = (int16_t)((int32_t)(0x7FFFFFFFu - tr) / 0x10000);
         field[idx] = v;
+        if (transl_cropped) transl_cropped[idx] = tr;
     }
 }
 

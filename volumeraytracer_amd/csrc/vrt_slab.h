@@ -122,7 +122,7 @@ __device__ __forceinline__ void gather_lds(const LV *seg, uint32_t base, uint32_
 
 // VPL = voxels staged per lane at most; the wave's LDS segment holds 64*VPL fp32 voxels (16 B each).
 // OCC = waves per SIMD the register allocator must allow (launch-bounds second argument).
-template <typename FieldT, typename DirT, int VPL, int OCC>
+template <typename FieldT, typename DirT, int VPL, int OCC, bool ABSORB>
 __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(const MarchParams p)
 {
     using vox = typename FieldTraits<FieldT>::vox;
@@ -150,6 +150,7 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
     // `rem_w` and zeroes `it`, so "it > 0 and inside the field" is the only liveness predicate.
     uint32_t it = have ? p.iterations - 1 : 0u;
     uint32_t rem_w = 0xFFFFFFFFu;
+    uint32_t light = 0xFFFFFFFFu;                       // brightness, ABSORB only (.cu:332)
 
     for (;;) {
         const bool live = it > 0 && in_field(r, bx1, by1, bz1);
@@ -210,9 +211,14 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                 if (__ballot(alive) == 0ull) break;
                 stat_add(p, kStatDirectWaveSteps, 1);
                 if (alive) {
-                    f4 c[8];
-                    gather_global<FieldT>(f, r, p.By, p.Bz, c);
-                    if (march_step(r, c, invx, invy, invz)) { rem_w = it; it = 0; } else --it;
+                    bool dark = false;
+                    if constexpr (ABSORB) dark = absorb_step(p, r, light);
+                    if (dark) { rem_w = it; it = 0; }
+                    else {
+                        f4 c[8];
+                        gather_global<FieldT>(f, r, p.By, p.Bz, c);
+                        if (march_step(r, c, invx, invy, invz)) { rem_w = it; it = 0; } else --it;
+                    }
                 }
             }
             continue;
@@ -272,33 +278,38 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                 if (__ballot(alive) == 0ull) break;
                 stat_add(p, kStatLdsWaveSteps, 1);
                 if (alive) {
-                    f4 c[8];
-                    gather_lds(seg, __umul24(__umul24(cx, ey) + cy, ez) + cz, sy, sx, c);
-                    if (march_step(r, c, invx, invy, invz, brick_has_w)) { rem_w = it; it = 0; } else --it;
+                    bool dark = false;
+                    if constexpr (ABSORB) dark = absorb_step(p, r, light);
+                    if (dark) { rem_w = it; it = 0; }
+                    else {
+                        f4 c[8];
+                        gather_lds(seg, __umul24(__umul24(cx, ey) + cy, ez) + cz, sy, sx, c);
+                        if (march_step(r, c, invx, invy, invz, brick_has_w)) { rem_w = it; it = 0; } else --it;
+                    }
                 }
             }
         }
     }
-    if (have) store_ray<DirT>(p, ray, r, rem_w != 0xFFFFFFFFu ? rem_w : it);
+    if (have) store_ray<DirT>(p, ray, r, rem_w != 0xFFFFFFFFu ? rem_w : it, light);
 }
 
-template <typename FieldT, typename DirT, int VPL, int OCC>
+template <typename FieldT, typename DirT, int VPL, int OCC, bool ABSORB>
 hipError_t launch_slab_vpl(const MarchParams &p, hipStream_t s)
 {
     const unsigned threads = 64 * kSlabWavesPerBlock;
     const unsigned grid = (p.nrays + threads - 1) / threads;
     const size_t lds = sizeof(typename LdsVox<FieldT>::type) * 64 * VPL * kSlabWavesPerBlock;
-    k_march_slab<FieldT, DirT, VPL, OCC><<<grid, threads, lds, s>>>(p);
+    k_march_slab<FieldT, DirT, VPL, OCC, ABSORB><<<grid, threads, lds, s>>>(p);
     return hipGetLastError();
 }
 
 // slab_lds_bytes selects the LDS segment per wave (0 = default).  The voxel count per lane and the
 // register budget (waves per SIMD the allocator must allow) both follow from the byte size:
 // 160 KiB LDS / CU and 512 VGPRs per SIMD lane give 8 waves/SIMD at <= 5 KiB, 6 at 6 KiB, 5 at 8 KiB ...
-template <typename FieldT, typename DirT, int BYTES, int OCC>
+template <typename FieldT, typename DirT, int BYTES, int OCC, bool ABSORB = false>
 hipError_t launch_slab_bytes(const MarchParams &p, hipStream_t s)
 {
-    return launch_slab_vpl<FieldT, DirT, BYTES / (64 * (int)sizeof(typename LdsVox<FieldT>::type)), OCC>(p, s);
+    return launch_slab_vpl<FieldT, DirT, BYTES / (64 * (int)sizeof(typename LdsVox<FieldT>::type)), OCC, ABSORB>(p, s);
 }
 
 template <typename FieldT, typename DirT>
@@ -310,6 +321,10 @@ hipError_t launch_slab(MarchParams p, bool /*path*/, int num_cu, hipStream_t s)
     if (want == 0) {
         const uint64_t waves_per_cu = ((uint64_t)p.nrays + 63) / 64 / (uint64_t)(num_cu > 0 ? num_cu : 256);
         want = waves_per_cu <= 20 ? 8192u : 6144u;
+    }
+    if (p.transl) {                                    // opt-in absorption mode: the two default sizes only
+        if (want <= 6144) return launch_slab_bytes<FieldT, DirT, 6144, 6, true>(p, s);
+        return launch_slab_bytes<FieldT, DirT, 8192, 5, true>(p, s);
     }
     if (want <= 4096) return launch_slab_bytes<FieldT, DirT, 4096, 8>(p, s);
     if (want <= 5120) return launch_slab_bytes<FieldT, DirT, 5120, 8>(p, s);
