@@ -152,6 +152,9 @@ def main():
     ap.add_argument("--iterations", type=int, default=100000)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget; 0 disables it")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
+    ap.add_argument("--rehearse", action="store_true",
+                    help="development: let several ranks share one GPU (local_rank %% device_count) to exercise the "
+                         "multi-rank code path on a single-GPU box; timings are meaningless")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -166,13 +169,19 @@ def main():
         if rank == 0:
             print("[bench]", *a, file=sys.stderr, flush=True)
 
+    if args.rehearse:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+        if args.rehearse:
+            dist.init_process_group(backend="gloo")                # RCCL refuses two ranks on one GPU
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+    cdev = torch.device("cpu") if args.rehearse else dev           # where the collectives' tensors live
 
     cfg = CONFIGS[args.config]
     N = cfg["N"]
@@ -213,7 +222,7 @@ def main():
         eng.trace_device(capi.VRT_F32, n, d_sp.data_ptr(), d_sd.data_ptr(), o_ep.data_ptr(), o_ed.data_ptr(),
                          o_ei.data_ptr(), o_rl.data_ptr(), inv, args.iterations, stream=stream, options=opts)
         if world > 1:
-            D.gather_records(out, counts, dst=0)
+            D.gather_records(out.to(cdev), counts, dst=0)
 
     for _ in range(args.warmup):
         step()
@@ -230,7 +239,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_begin
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -251,7 +260,7 @@ def main():
     steps_local = int(o_ei.to(torch.int64).sum().item())
     steps_total = steps_local
     if world > 1:
-        t = torch.tensor([steps_local], dtype=torch.int64, device=dev)
+        t = torch.tensor([steps_local], dtype=torch.int64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         steps_total = int(t.item())
 
