@@ -158,6 +158,21 @@ def test_path_chunking_and_caps():
     assert np.all(got["end_iteration"] == 30)
 
 
+def test_path_tracing_in_many_chunks(monkeypatch):
+    """vrt_trace cuts path tracing into ray chunks bounded by a device path budget (2 GiB by default, like
+    the reference's 0x8000-ray chunks, .cu:798-840); shrink the budget so 300 rays need 7 chunks."""
+    N = 24
+    bounds, dx, dy, dz, tc = W.seam_field(N, np.float32, opaque_radius=3.0)
+    field = oracle.port.interleave(dx, dy, dz, tc)
+    sp, sd = W.random_rays(N, 300, seed=8)
+    cap = 70
+    want = oracle.port.trace(field, bounds, sp, sd, [1, 1, 1], cap, trace_paths=True)
+    monkeypatch.setenv("VRT_PATH_BUDGET_BYTES", str(45 * cap * 12))      # 45 rays per chunk
+    with capi.Engine.from_host(bounds, [dx, dy, dz], tc) as eng:
+        got = eng.trace(sp, sd, [1, 1, 1], cap, trace_paths=True, options=capi.default_options(loglevel=-1))
+    _assert_same(got, want, keys=KEYS + ("path",))
+
+
 def test_create_from_device_and_trace_device():
     """Device-pointer entry points (what bench.py times): same bits as the host path."""
     torch = pytest.importorskip("torch")

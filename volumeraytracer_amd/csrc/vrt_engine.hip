@@ -337,7 +337,11 @@ int trace_host_impl(vrt_engine *e, int dir_type, size_t nrays, const uint32_t *s
     size_t chunk = nrays;
     if (path) {
         const size_t per_ray = (size_t)iterations * 12;
-        const size_t budget = (size_t)2 << 30;
+        size_t budget = (size_t)2 << 30;
+        if (const char *b = getenv("VRT_PATH_BUDGET_BYTES")) {          // tests shrink it to force several chunks
+            const unsigned long long v = strtoull(b, nullptr, 10);
+            if (v > 0) budget = (size_t)v;
+        }
         chunk = std::max<size_t>(1, std::min(nrays, budget / std::max<size_t>(per_ray, 1)));
     }
     HIP_TRY(e->h_in_pos.reserve(chunk * 12));
