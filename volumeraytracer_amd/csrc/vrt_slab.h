@@ -36,7 +36,14 @@ constexpr int kSlabWavesPerBlock = 4;
 #define VRT_SLAB_MAXK 192
 #endif
 constexpr int kSlabMaxK = VRT_SLAB_MAXK;   // longest planned round, steps
-constexpr int kSlabDirectSteps = 16;    // global-gather steps for a wave that fits no brick
+#ifndef VRT_SLAB_DIRECT_STEPS
+#define VRT_SLAB_DIRECT_STEPS 64
+#endif
+constexpr int kSlabDirectSteps = VRT_SLAB_DIRECT_STEPS;    // global-gather steps before re-planning for a wave that stages no brick
+#ifndef VRT_SLAB_MINK
+#define VRT_SLAB_MINK 8
+#endif
+constexpr int kSlabMinK = VRT_SLAB_MINK; // rounds shorter than this are not worth staging: gather from global memory
 
 __device__ __forceinline__ uint32_t sgpr(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
             if (v2 <= kCap) { K = K2; vol = v2; bk = b2; }
         }
 
-        if (vol > kCap || bk.e[0] < 2 || bk.e[1] < 2 || bk.e[2] < 2) {
+        if (vol > kCap || K < kSlabMinK || bk.e[0] < 2 || bk.e[1] < 2 || bk.e[2] < 2) {
             // ---- incoherent wave: gather from global memory for a few steps, then re-plan ----
             stat_add(p, kStatDirectRounds, 1);
 #ifdef VRT_SLAB_STATS
