@@ -254,6 +254,10 @@ def test_torture_rare_paths(fdt, kernel):
     dirs *= scale[:, None]
     dirs[::97] = 0.0                                                           # exactly collapsed directions
     dirs[5::101, 1:] = 0.0
+    dirs[7::113, 0] = np.inf                                                   # one infinite component: step = inf * 0 = NaN there only
+    dirs[11::127, 2] = -np.inf
+    dirs[13::131, 1] = np.nan                                                  # NaN direction component
+    dirs[17::137] = 3.0e38                                                     # |dir|^2 overflows
     sd = dirs.reshape(-1)
     with capi.Engine.from_host(B, d, tc) as eng:
         for inv in ([1, 1, 1], [7.5, 0.25, 3.0], [1e-3, 1e3, 1.0]):

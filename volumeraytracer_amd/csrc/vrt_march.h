@@ -142,7 +142,8 @@ __device__ __forceinline__ bool march_step(Ray &r, const f4 (&c)[8], float invx,
     // trunc >= 0 that is (t+1)>>1, for trunc < 0 it is floor(t/2), i.e. round half away from zero.
     const float ilen2 = ilen + ilen;
     const float tx = (r.dx * invx) * ilen2, ty = (r.dy * invy) * ilen2, tz = (r.dz * invz) * ilen2;
-    if (fmaxf(fmaxf(__builtin_fabsf(tx), __builtin_fabsf(ty)), __builtin_fabsf(tz)) < 2147483648.0f) {
+    // the sum (not fmaxf, which drops NaNs) so that a NaN or infinity in ANY component takes the slow path
+    if (__builtin_fabsf(tx) + __builtin_fabsf(ty) + __builtin_fabsf(tz) < 2147483648.0f) {
         r.px += round_half_i32(tx);                         // |s| < 2^30: always, unless the direction has collapsed
         r.py += round_half_i32(ty);
         r.pz += round_half_i32(tz);

@@ -334,7 +334,7 @@ hipError_t launch_slab(MarchParams p, bool /*path*/, int num_cu, hipStream_t s)
         return launch_slab_bytes<FieldT, DirT, 8192, 5, true>(p, s);
     }
     if (want <= 4096) return launch_slab_bytes<FieldT, DirT, 4096, 8>(p, s);
-    if (want <= 5120) return launch_slab_bytes<FieldT, DirT, 5120, 8>(p, s);
+    if (want <= 5120) return launch_slab_bytes<FieldT, DirT, 5120, 7>(p, s);
     if (want <= 6144) return launch_slab_bytes<FieldT, DirT, 6144, 6>(p, s);
     if (want <= 8192) return launch_slab_bytes<FieldT, DirT, 8192, 5>(p, s);
     if (want <= 12288) return launch_slab_bytes<FieldT, DirT, 12288, 3>(p, s);
