@@ -198,6 +198,7 @@ def main():
         eng = scene.engine()
         bounds = [N - 2] * 3
         d = tr = None
+        lut_host = (dens, lut_ior, lut_tr)                       # kept for the CPU baseline leg only
     else:
         bounds, d, tr = synth_field_device(N, cfg["field"], dev, opaque=cfg.get("opaque", False))
         torch.cuda.synchronize()
@@ -300,10 +301,17 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel_ms": kavg_ms, "algorithmic_bytes_per_ray_step": bytes_per_step},
     }
-    if args.cpu_seconds > 0 and d is not None and world == 1:      # CPU baseline: rank 0 at N = 1 only
-        host = [x.cpu().numpy() for x in d]
-        tc_host = tr.cpu().numpy().view(np.uint32)
+    if args.cpu_seconds > 0 and world == 1:                        # CPU baseline: rank 0 at N = 1 only
         import oracle
+        if d is not None:
+            host = [x.cpu().numpy() for x in d]
+            tc_host = tr.cpu().numpy().view(np.uint32)
+        else:                                                      # LUT scene: expand and build on the CPU checker too
+            t0 = time.time()
+            dens, lut_ior, lut_tr = lut_host
+            hx, hy, hz, tc_host, _ = oracle.port.scene_build([N, N, N], lut_ior[dens], lut_tr[dens])
+            host = [hx, hy, hz]
+            log("CPU scene build (oracle, untimed for the baseline): %.1f s" % (time.time() - t0))
         field_host = oracle.port.interleave(host[0], host[1], host[2], tc_host)
         del host
         gpu_out = dict(end_position=o_ep.cpu().numpy().view(np.uint32),
