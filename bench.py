@@ -136,8 +136,41 @@ def cpu_baseline(field_host, bounds, sp, sd, inv, iterations, gpu_out, budget_s,
                              gpu_out["end_direction"].reshape(-1, 3)[idx].view(np.uint32)))
     res = {"value": steps / dt, "unit": "ray-steps/s", "cores": threads, "kind": "port",
            "sample": "%d of %d rays (evenly strided), %d ray-steps, %.2f s, OpenMP %d threads" % (m, n, steps, dt, threads),
-           "gpu_matches_bit_exact": bool(ok)}
+           "gpu_matches_bit_exact": bool(ok), "cpu_model": cpu_model()}
+    # also the 1-thread rate, on a sample sized for about 2 s
+    m1 = int(min(n, max(64, 2.0 * 1.8e7 / max(mean_steps, 1.0))))     # one core does about 1.8e7 ray-steps/s
+    idx = np.linspace(0, n - 1, m1).astype(np.int64)
+    t0 = time.time()
+    out = oracle.port.trace(field_host, bounds, sp3[idx].reshape(-1), sd3[idx].reshape(-1), inv, iterations, nthreads=1)
+    dt = max(time.time() - t0, 1e-6)
+    res["one_thread"] = {"value": int(out["end_iteration"].astype(np.int64).sum()) / dt, "unit": "ray-steps/s",
+                         "sample": "%d rays, %.2f s" % (m1, dt)}
     return res
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def device_copy_gbs(dev, nbytes=1 << 30, reps=5):
+    """Measured HBM copy bandwidth (read + written bytes / time) -- context for the 8 TB/s vendor peak."""
+    a = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def main():
@@ -299,7 +332,8 @@ def main():
                    "kernel": args.kernel, "sort": args.sort, "parallelism": "rays sharded in %d row bands, field replicated, RCCL gather to rank 0" % world if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel_ms": kavg_ms, "algorithmic_bytes_per_ray_step": bytes_per_step},
+                     "kernel_ms": kavg_ms, "algorithmic_bytes_per_ray_step": bytes_per_step,
+                     "compulsory_bytes": eng.field_bytes, "measured_copy_GBps": device_copy_gbs(dev)},
     }
     if args.cpu_seconds > 0 and world == 1:                        # CPU baseline: rank 0 at N = 1 only
         import oracle
