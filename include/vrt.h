@@ -152,6 +152,11 @@ float vrt_engine_last_march_ms(vrt_handle h);
 /* Development aid: with VRT_DEBUG_STATS=1 in the environment the slab kernel counts planning
  * rounds / staged voxels / LDS steps; this copies up to n (<= 64) counters of the last launch. */
 int vrt_engine_debug_stats(vrt_handle h, unsigned long long *out, int n);
+/* Exhaustive device self-test of the march step's short replacement for the reference's IEEE divide
+ * 0x42000000p0f / dot (cuda_volume_raytracer.cu:346): for every float bit pattern the short path admits,
+ * compares it with the IEEE quotient.  *mismatches must come back 0; *admitted = number of patterns
+ * taking the short path (219 exponents x 2^23 mantissas). */
+int vrt_selftest_ilen2(int device, unsigned long long *mismatches, unsigned long long *admitted);
 
 /* ---------------------------------------------------------------------------------------------
  * Scene layer: the reference's RaytraceScene<Ior,IorLog,Diff>

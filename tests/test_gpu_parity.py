@@ -270,3 +270,13 @@ def test_torture_rare_paths(fdt, kernel):
         sdi[::50] = 0
         want = oracle.port.trace(field, B, sp, sdi, [1, 2, 0.5], 3000)
         _assert_same(eng.trace(sp, sdi, [1, 2, 0.5], 3000, options=_opts(kernel)), want, ctx="i16 dirs")
+
+
+@pytest.mark.gpu
+def test_short_division_is_exact_for_every_admitted_float():
+    """march_step replaces the reference's IEEE divide 0x42000000p0f / dot (.cu:346) by rcp + one fma
+    refinement inside an exponent window; the device sweeps every float bit pattern (both signs, all
+    exponents, all 2^23 mantissas) and compares with the IEEE quotient.  Integer-exact: 0 mismatches."""
+    bad, admitted = capi.selftest_ilen2(0)
+    assert bad == 0
+    assert admitted == (251 - 32) * (1 << 23)          # positive d with biased exponent 32..250, nothing else

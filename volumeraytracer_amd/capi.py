@@ -18,7 +18,7 @@ KERNEL_AUTO, KERNEL_DIRECT, KERNEL_SLAB = 0, 1, 2
 ABI_SYMBOLS = (
     "vrt_options_default", "vrt_device_count", "vrt_abi_version", "vrt_create", "vrt_create_from_device",
     "vrt_trace", "vrt_trace_device", "vrt_destroy", "vrt_engine_device", "vrt_engine_field_bytes",
-    "vrt_engine_field_device_ptr", "vrt_engine_last_march_ms", "vrt_engine_debug_stats",
+    "vrt_engine_field_device_ptr", "vrt_engine_last_march_ms", "vrt_engine_debug_stats", "vrt_selftest_ilen2",
     "vrt_last_error", "vrt_scene_create", "vrt_scene_create_lut", "vrt_scene_trace", "vrt_scene_destroy", "vrt_scene_engine",
 )
 
@@ -85,6 +85,8 @@ def load():
     L.vrt_engine_field_device_ptr.argtypes = [vp]
     L.vrt_engine_field_device_ptr.restype = vp
     L.vrt_engine_debug_stats.argtypes = [vp, C.POINTER(C.c_ulonglong), C.c_int]
+    if hasattr(L, "vrt_selftest_ilen2"):            # absent only in older A/B builds selected through VRT_LIB
+        L.vrt_selftest_ilen2.argtypes = [C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     L.vrt_engine_last_march_ms.argtypes = [vp]
     L.vrt_engine_last_march_ms.restype = C.c_float
     if hasattr(L, "vrt_scene_create"):
@@ -117,6 +119,13 @@ def default_options(**kw):
 
 def device_count():
     return int(load().vrt_device_count())
+
+
+def selftest_ilen2(device=0):
+    """Exhaustive device check of the short division in the march step -> (mismatches, admitted patterns)."""
+    bad, adm = C.c_ulonglong(0), C.c_ulonglong(0)
+    check(load().vrt_selftest_ilen2(int(device), C.byref(bad), C.byref(adm)))
+    return int(bad.value), int(adm.value)
 
 
 def _np_ptr(a):

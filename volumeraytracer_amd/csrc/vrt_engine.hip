@@ -414,6 +414,24 @@ struct vrt_scene {
 // C ABI
 // =============================================================================================
 
+
+// Exhaustive self-test of the march step's short division (vrt_march.h: ilen2_short / div_window):
+// one block per (sign, biased exponent), threads sweep all 2^23 mantissas.
+__global__ __launch_bounds__(256) void k_selftest_ilen2(unsigned long long *out /* [2]: mismatches, admitted */)
+{
+    const uint32_t expo = blockIdx.x & 255u, sign = blockIdx.x >> 8;
+    unsigned long long bad = 0, adm = 0;
+    for (uint32_t m = threadIdx.x; m < (1u << 23); m += blockDim.x) {
+        const float d = __uint_as_float((sign << 31) | (expo << 23) | m);
+        if (!vrt::div_window(d)) continue;
+        ++adm;
+        const float q = 0x42000000p0f / d;                                   // IEEE divide, as .cu:346
+        bad += __float_as_uint(vrt::ilen2_short(d)) != __float_as_uint(q + q);
+    }
+    for (int o = 32; o > 0; o >>= 1) { bad += __shfl_xor(bad, o); adm += __shfl_xor(adm, o); }
+    if ((threadIdx.x & 63u) == 0) { atomicAdd(&out[0], bad); atomicAdd(&out[1], adm); }
+}
+
 extern "C" {
 
 void vrt_options_default(vrt_options *opt)
@@ -767,6 +785,24 @@ float vrt_engine_last_march_ms(vrt_handle h)
     if (hipEventSynchronize(h->ev_end) != hipSuccess) return -1.0f;
     if (hipEventElapsedTime(&ms, h->ev_begin, h->ev_end) != hipSuccess) return -1.0f;
     return ms;
+}
+
+int vrt_selftest_ilen2(int device, unsigned long long *mismatches, unsigned long long *admitted)
+{
+    if (!mismatches || !admitted) return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_selftest_ilen2: null output");
+    DeviceGuard g(device);
+    if (!g.ok) return fail(VRT_ERR_NO_DEVICE, "vrt_selftest_ilen2: cannot select device");
+    unsigned long long *d_out = nullptr, h_out[2] = {0, 0};
+    HIP_TRY(hipMalloc(&d_out, sizeof(h_out)));
+    hipError_t e = hipMemset(d_out, 0, sizeof(h_out));
+    if (e == hipSuccess) { k_selftest_ilen2<<<512, 256>>>(d_out); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(h_out, d_out, sizeof(h_out), hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);
+    HIP_TRY(e);
+    *mismatches = h_out[0];
+    *admitted = h_out[1];
+    return VRT_OK;
 }
 
 }  // extern "C"

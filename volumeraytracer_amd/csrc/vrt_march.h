@@ -67,6 +67,21 @@ __device__ __forceinline__ uint32_t round_half_i32(float t)
     return (uint32_t)((i + 1 + (i >> 31)) >> 1);
 }
 
+// 2 * (0x42000000p0f / d) without the 11-instruction IEEE sequence: v_rcp_f32 (1 ulp) and one fma
+// refinement of the quotient.  tools/ubench/div_exact.hip and vrt_selftest_ilen2() compare this against
+// the IEEE divide for EVERY mantissa of every exponent: it is bit-identical for biased exponents 31..252
+// of d (below, the quotient overflows; above, the reciprocal is denormal).  div_window() admits 32..250.
+__device__ __forceinline__ bool div_window(float d)
+{
+    return (__float_as_uint(d) - (32u << 23)) < ((251u - 32u) << 23);   // sign bit set / NaN / inf wrap out of range
+}
+__device__ __forceinline__ float ilen2_short(float d)
+{
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float q = 0x84000000p0f * r;
+    return fma_(fma_(-d, q, 0x84000000p0f), r, q);
+}
+
 // ---- voxel pair loads: voxel z and z+1 at one (x,y), as 2 x f4 --------------------------
 
 typedef float   vox_f32 __attribute__((ext_vector_type(4)));   // 16 B: {dx, dy, dz, w}
@@ -135,15 +150,19 @@ __device__ __forceinline__ bool march_step(Ray &r, const f4 (&c)[8], float invx,
     r.dy = fma_(g[1], invy, r.dy);
     r.dz = fma_(g[2], invz, r.dz);
     const float dot = fma_(r.dz, r.dz, fma_(r.dx, r.dx, r.dy * r.dy));
-    const float ilen = 0x42000000p0f / dot;                 // IEEE divide (.cu:346)
-    // The step s = (dir*inv)*ilen (.cu:347) is needed only through roundf(s).  Doubling is exact and
-    // commutes with the rounding of the product, so t = (dir*inv)*(2*ilen) == 2s bit for bit; its
-    // truncation keeps the half bit and roundf(s) == (trunc(2s) + 1 + sign) >> 1 (arithmetic): for
-    // trunc >= 0 that is (t+1)>>1, for trunc < 0 it is floor(t/2), i.e. round half away from zero.
-    const float ilen2 = ilen + ilen;
+    // The step s = (dir*inv)*ilen, ilen = 0x42000000p0f / dot (IEEE divide, .cu:346-347), is needed only
+    // through roundf(s).  Doubling is exact and commutes with the rounding of the product, so
+    // t = (dir*inv)*(2*ilen) == 2s bit for bit; its truncation keeps the half bit and
+    // roundf(s) == (trunc(2s) + 1 + sign) >> 1 (arithmetic): for trunc >= 0 that is (t+1)>>1, for
+    // trunc < 0 it is floor(t/2), i.e. round half away from zero.
+    const bool tame = div_window(dot);                      // false for NaN, inf, negative, tiny and huge dot
+    float ilen2;
+    if (tame) ilen2 = ilen2_short(dot);                     // == 2 * (0x42000000p0f / dot), proven exhaustively
+    else { const float ilen = 0x42000000p0f / dot; ilen2 = ilen + ilen; }
     const float tx = (r.dx * invx) * ilen2, ty = (r.dy * invy) * ilen2, tz = (r.dz * invz) * ilen2;
-    // the sum (not fmaxf, which drops NaNs) so that a NaN or infinity in ANY component takes the slow path
-    if (__builtin_fabsf(tx) + __builtin_fabsf(ty) + __builtin_fabsf(tz) < 2147483648.0f) {
+    // tame dot => dir and inv are finite and ilen2 is finite and nonzero, so t is finite or +-inf, never
+    // NaN, and fmaxf (which would drop a NaN) is a safe range test; everything else rounds the slow way
+    if (tame && fmaxf(fmaxf(__builtin_fabsf(tx), __builtin_fabsf(ty)), __builtin_fabsf(tz)) < 2147483648.0f) {
         r.px += round_half_i32(tx);                         // |s| < 2^30: always, unless the direction has collapsed
         r.py += round_half_i32(ty);
         r.pz += round_half_i32(tz);
