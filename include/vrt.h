@@ -57,7 +57,8 @@ typedef struct vrt_options {
     uint64_t max_cpu;        /* _max_cpu (256): kept for ABI parity; unused (no CPU path) */
     int32_t  device;         /* extension: HIP device ordinal, -1 = current device */
     int32_t  kernel;         /* extension: VRT_KERNEL_* selector, 0 = auto */
-    int32_t  sort_rays;      /* extension: 0 = auto, 1 = tile ordering, 2 = tile ordering longest-first, -1 = keep caller order */
+    int32_t  sort_rays;      /* extension: 0 = auto (3 for >= 4096 rays), 1 = tile ordering, 2 = tile ordering with per-ray length buckets,
+                                3 = tile ordering + wavefronts launched longest-first, -1 = keep caller order */
     int32_t  slab_lds_bytes; /* extension: LDS bytes per wavefront for the slab kernel, 0 = default */
     int32_t  absorption;     /* extension, opt-in: 1 = run the absorption branch the reference compiles out
                               * (cuda_volume_raytracer.cu:337-341): per step brightness -= min(brightness,
@@ -150,7 +151,8 @@ const void *vrt_engine_field_device_ptr(vrt_handle h);
  * Negative if nothing has been launched.  Used by bench.py for the roofline figure. */
 float vrt_engine_last_march_ms(vrt_handle h);
 /* Development aid: with VRT_DEBUG_STATS=1 in the environment the slab kernel counts planning
- * rounds / staged voxels / LDS steps; this copies up to n (<= 64) counters of the last launch. */
+ * rounds / staged voxels / LDS steps; this copies up to n counters of the last launch (64 counters, then,
+ * in -DVRT_SLAB_TIMELINE development builds, a begin/end clock pair per wavefront). */
 int vrt_engine_debug_stats(vrt_handle h, unsigned long long *out, int n);
 /* Exhaustive device self-test of the march step's short replacement for the reference's IEEE divide
  * 0x42000000p0f / dot (cuda_volume_raytracer.cu:346): for every float bit pattern the short path admits,

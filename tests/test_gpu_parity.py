@@ -112,9 +112,33 @@ def test_vs_oracle_incoherent(kernel):
     sp, sd = W.random_rays(N, 5000, seed=17, vol_seed=3)
     want = oracle.port.trace(field, bounds, sp, sd, [1, 1, 1], 100000)
     with capi.Engine.from_host(bounds, [dx, dy, dz], tc) as eng:
-        for sort in (-1, 1):
+        for sort in (-1, 1, 2, 3):
             got = eng.trace(sp, sd, [1, 1, 1], 100000, options=_opts(kernel, sort))
             _assert_same(got, want, ctx="sort%d" % sort)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("fdt", [np.float32, np.int16])
+@pytest.mark.parametrize("ddt", [np.float32, np.int16])
+def test_longest_first_wavefront_order(fdt, ddt, kernel):
+    """sort_rays = 3: tile order + wavefronts launched longest-first from the coarse-march estimate (the
+    auto mode above 24 wavefronts per CU).  Only the launch order may change -- results stay bit-identical,
+    including a ragged last wavefront, NaN / inf directions and rays that start outside the field."""
+    N = 48
+    bounds, dx, dy, dz, tc = W.seam_field(N, fdt, opaque_radius=5.0)
+    field = oracle.port.interleave(dx, dy, dz, tc)
+    sp, sd = W.perspective_rays(N, 75, dir_dtype=ddt)                     # 5625 rays = 87 wavefronts + 57 rays
+    sp, sd = sp.copy(), sd.copy()
+    sp.reshape(-1, 3)[3::211] = 0xFFF00000                                 # outside the field
+    if ddt == np.float32:
+        sd.reshape(-1, 3)[5::173, 1] = np.nan
+        sd.reshape(-1, 3)[7::191, 0] = np.inf
+        sd.reshape(-1, 3)[11::197] = 0.0
+    for inv, cap in (([1, 1, 1], 100000), ([0.5, 1, 2], 700)):
+        want = oracle.port.trace(field, bounds, sp, sd, inv, cap)
+        with capi.Engine.from_host(bounds, [dx, dy, dz], tc) as eng:
+            got = eng.trace(sp, sd, inv, cap, options=_opts(kernel, 3))
+            _assert_same(got, want, ctx="inv=%s cap=%d" % (inv, cap))
 
 
 @pytest.mark.parametrize("kernel", KERNELS)

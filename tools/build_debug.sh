@@ -6,4 +6,6 @@ cd "$(dirname "$0")/.."
 mkdir -p tmp_libs
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-slp-vectorize -DVRT_SLAB_STATS \
     -o tmp_libs/libvrt_stats.so volumeraytracer_amd/csrc/vrt_engine.hip
-echo tmp_libs/libvrt_stats.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-slp-vectorize -DVRT_SLAB_TIMELINE \
+    -o tmp_libs/libvrt_timeline.so volumeraytracer_amd/csrc/vrt_engine.hip
+echo tmp_libs/libvrt_stats.so tmp_libs/libvrt_timeline.so

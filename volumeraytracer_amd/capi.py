@@ -189,6 +189,13 @@ class Engine:
     def field_bytes(self):
         return int(load().vrt_engine_field_bytes(self._h))
 
+    def debug_raw(self, n):
+        """First n raw 64-bit debug words of the last launch (needs VRT_DEBUG_STATS=1): 64 counters, then the
+        per-wavefront begin/end clocks of a -DVRT_SLAB_TIMELINE development build."""
+        buf = (C.c_ulonglong * int(n))()
+        check(load().vrt_engine_debug_stats(self._h, buf, int(n)))
+        return np.frombuffer(buf, dtype=np.uint64).copy()
+
     def debug_stats(self):
         """Slab-kernel debug counters of the last launch (needs VRT_DEBUG_STATS=1)."""
         buf = (C.c_ulonglong * 16)()

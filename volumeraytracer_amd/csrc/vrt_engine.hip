@@ -94,6 +94,7 @@ struct vrt_engine {
     DevBuf sort_keys, sort_keys_alt, sort_vals, sort_vals_alt, sort_tmp, sort_bounds;
     DevBuf transl;                 // translucency per field voxel, kept only for the opt-in absorption mode
     DevBuf stats;                  // debug counters, allocated only when VRT_DEBUG_STATS=1
+    size_t stats_count = 0;
     DevBuf h_in_pos, h_in_dir, h_out_pos, h_out_dir, h_out_iter, h_out_light, h_path;
     vrt_options opt;
 };
@@ -252,6 +253,7 @@ int trace_device_impl(vrt_engine *e, int dir_type, size_t nrays, const uint32_t 
     p.end_pos = d_ep; p.end_dir = d_ed; p.end_iter = d_ei; p.remaining_light = d_rl;
     p.path = d_path;
     p.order = nullptr;
+    p.wave_order = nullptr;
     p.iterations = iterations;
     p.nrays = (uint32_t)nrays;
     p.out_pos_bias = out_pos_bias;
@@ -272,8 +274,10 @@ int trace_device_impl(vrt_engine *e, int dir_type, size_t nrays, const uint32_t 
 
     p.stats = nullptr;
     if (const char *dbg = getenv("VRT_DEBUG_STATS"); dbg && dbg[0] == '1') {
-        HIP_TRY(e->stats.reserve(64 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemsetAsync(e->stats.p, 0, 64 * sizeof(unsigned long long), s));
+        // 64 counters, then (development builds with -DVRT_SLAB_TIMELINE) 4 words per wavefront
+        e->stats_count = 64 + 4 * (((size_t)nrays + 63) / 64);
+        HIP_TRY(e->stats.reserve(e->stats_count * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(e->stats.p, 0, e->stats_count * sizeof(unsigned long long), s));
         p.stats = (unsigned long long *)e->stats.p;
     }
     int kernel = o.kernel;
@@ -285,12 +289,17 @@ int trace_device_impl(vrt_engine *e, int dir_type, size_t nrays, const uint32_t 
     // tile ordering: group rays that enter the field close together into the same wavefront
     const bool sort = o.sort_rays > 0 || (o.sort_rays == 0 && nrays >= 4096);
     if (sort) {
-        const uint32_t *order = nullptr;
+        const uint32_t *order = nullptr, *wave_order = nullptr;
+        // longest wavefronts first: always for 3; in auto mode only when the launch has more wavefronts than the
+        // GPU holds at once (24 per CU at the default LDS segment) -- otherwise every wavefront starts at t = 0 anyway
+        const int wave_lpt = !d_path && (o.sort_rays == 3 || (o.sort_rays == 0 && (nrays + 63) / 64 > (size_t)e->num_cu * 24));
         hipError_t se = vrt::build_tile_order(d_sp, d_sd, dir_type, (uint32_t)nrays, e->B[0], e->B[1], e->B[2], o.sort_rays == 2 ? 1 : 0, e->sort_keys, e->sort_keys_alt,
-                                              e->sort_vals, e->sort_vals_alt, e->sort_tmp, e->sort_bounds, s, &order);
+                                              e->sort_vals, e->sort_vals_alt, e->sort_tmp, e->sort_bounds, s, &order,
+                                              wave_lpt, iterations, &wave_order, e->field, e->field_type == VRT_I16, invscale);
         if (se != hipSuccess) return fail(se == hipErrorOutOfMemory ? VRT_ERR_OUT_OF_MEMORY : VRT_ERR_HIP,
                                           "ray tile ordering failed: %s", hipGetErrorString(se));
         p.order = order;
+        p.wave_order = wave_order;
     }
 
     HIP_TRY(hipEventRecord(e->ev_begin, s));
@@ -773,7 +782,7 @@ int vrt_engine_debug_stats(vrt_handle h, unsigned long long *out, int n)
     if (!h->stats.p) return fail(VRT_ERR_INVALID_ARGUMENT, "debug stats not enabled (set VRT_DEBUG_STATS=1)");
     DeviceGuard g(h->device);
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, h->stats.p, sizeof(unsigned long long) * (size_t)std::min(n, 64), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, h->stats.p, sizeof(unsigned long long) * std::min((size_t)n, h->stats_count), hipMemcpyDeviceToHost));
     return VRT_OK;
 }
 

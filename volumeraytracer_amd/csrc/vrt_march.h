@@ -30,6 +30,7 @@ struct MarchParams {
     uint32_t *remaining_light;
     uint32_t *path;           // nullptr unless PATH
     const uint32_t *order;    // nullptr = identity; else ray processed by slot i is order[i]
+    const uint32_t *wave_order; // nullptr = identity; else the g-th launched wavefront takes slots 64*wave_order[g] ..+63
     uint32_t iterations;
     uint32_t nrays;
     uint32_t slab_lds_bytes;  // slab kernel: LDS bytes per wave
@@ -229,6 +230,15 @@ __device__ __forceinline__ void path_put(uint32_t *pb, uint32_t it, const Ray &r
     q[0] = r.px + bias; q[1] = r.py + bias; q[2] = r.pz + bias;
 }
 
+// slot processed by this thread: launch order of wavefronts (longest first, vrt_sort.h) x lane
+__device__ __forceinline__ uint32_t launch_slot(const MarchParams &p)
+{
+    const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    const uint32_t nw = (p.nrays + 63u) >> 6;
+    const uint32_t w = (p.wave_order && g < nw) ? p.wave_order[g] : g;
+    return w * 64u + lane;
+}
+
 // =========================================================================================
 // Kernel 1: DIRECT -- one lane per ray, corners gathered straight from the vector L1/L2.
 // =========================================================================================
@@ -254,7 +264,7 @@ template <typename FieldT, typename DirT, bool PATH, bool ABSORB>
 __global__ __launch_bounds__(256) void k_march_direct(const MarchParams p)
 {
     using vox = typename FieldTraits<FieldT>::vox;
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t slot = launch_slot(p);
     if (slot >= p.nrays) return;
     const uint32_t ray = p.order ? p.order[slot] : slot;
     Ray r;

@@ -19,6 +19,7 @@
 // the global gather for a few steps and re-plan.  Waves never synchronise with each other:
 // a 256-thread workgroup is four independent wavefronts with four LDS segments.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -46,6 +47,17 @@ constexpr int kSlabDirectSteps = VRT_SLAB_DIRECT_STEPS;    // global-gather step
 constexpr int kSlabMinK = VRT_SLAB_MINK; // rounds shorter than this are not worth staging: gather from global memory
 
 __device__ __forceinline__ uint32_t sgpr(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+// wave-uniform "some active lane has b": the compare mask itself (no 0/1 materialisation as with __ballot(int))
+__device__ __forceinline__ bool any_lane(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
+// a * b + c with a, b < 2^24 in one full-rate instruction (the compiler otherwise picks the quarter-rate
+// v_mad_u64_u32 for the brick address); b is wave-uniform
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ uint64_t lane_mask(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 
 // debug counters (MarchParams::stats != nullptr): per-wave events, added by lane 0
 enum { kStatRounds = 0, kStatPlannedK, kStatLdsWaveSteps, kStatDirectRounds, kStatDirectWaveSteps, kStatVoxStaged,
@@ -140,7 +152,7 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
     lvox *seg = (lvox *)smem + (size_t)wave * kCap;
 
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t slot = launch_slot(p);
     const bool have = slot < p.nrays;
     const uint32_t ray = have ? (p.order ? p.order[slot] : slot) : 0u;
     Ray r;
@@ -155,13 +167,20 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
     // completed step and the ray stops at it == 0, on leaving the field, or on w > 0; the value at
     // that moment is raydata._iterations.  A ray stopped by the w > 0 test parks that value in
     // `rem_w` and zeroes `it`, so "it > 0 and inside the field" is the only liveness predicate.
+#ifdef VRT_SLAB_TIMELINE   // development builds: 4 words per wavefront after the 64 counters (tools/timeline.py)
+    if (p.stats && lane == 0) p.stats[64 + 4 * (size_t)(slot >> 6)] = wall_clock64();
+    uint32_t tl_lds = 0, tl_dir = 0, tl_rounds = 0;
+#define VRT_TL(x) (x)
+#else
+#define VRT_TL(x) ((void)0)
+#endif
     uint32_t it = have ? p.iterations - 1 : 0u;
     uint32_t rem_w = 0xFFFFFFFFu;
     uint32_t light = 0xFFFFFFFFu;                       // brightness, ABSORB only (.cu:332)
 
     for (;;) {
         const bool live = it > 0 && in_field(r, bx1, by1, bz1);
-        if (__ballot(live) == 0ull) break;              // wave early-out: every lane has terminated
+        if (!any_lane(live)) break;              // wave early-out: every lane has terminated
 
         // ---- plan -------------------------------------------------------------------------
         int32_t s[3];
@@ -208,6 +227,7 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
         if (vol > kCap || K < kSlabMinK || bk.e[0] < 2 || bk.e[1] < 2 || bk.e[2] < 2) {
             // ---- incoherent wave: gather from global memory for a few steps, then re-plan ----
             stat_add(p, kStatDirectRounds, 1);
+            VRT_TL(++tl_rounds);
 #ifdef VRT_SLAB_STATS
             stat_add(p, 8, bk.e[0]); stat_add(p, 9, bk.e[1]); stat_add(p, 10, bk.e[2]);      // fallback brick extents (K = 1)
             stat_add(p, 11, (unsigned long long)__popcll(__ballot(live)));                    // live lanes at fallback
@@ -215,8 +235,9 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
 #endif
             for (int k = 0; k < kSlabDirectSteps; ++k) {
                 const bool alive = it > 0 && in_field(r, bx1, by1, bz1);
-                if (__ballot(alive) == 0ull) break;
+                if (!any_lane(alive)) break;
                 stat_add(p, kStatDirectWaveSteps, 1);
+                VRT_TL(++tl_dir);
                 if (alive) {
                     bool dark = false;
                     if constexpr (ABSORB) dark = absorb_step(p, r, light);
@@ -232,6 +253,7 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
         }
 
         stat_add(p, kStatRounds, 1);
+        VRT_TL(++tl_rounds);
         stat_add(p, kStatPlannedK, (unsigned long long)K);
         stat_add(p, kStatVoxStaged, vol);
         const uint32_t ey = bk.e[1], ez = bk.e[2];
@@ -262,7 +284,7 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                 wpos |= tmp[j].w > 0;                                 // lanes past the end re-read voxel 0: harmless
                 if (v < vol) seg[v] = to_lds_vox(tmp[j]);
             }
-            brick_has_w = __ballot(wpos) != 0ull;                     // wave-uniform: any opaque-ish voxel staged?
+            brick_has_w = any_lane(wpos);                     // wave-uniform: any opaque-ish voxel staged?
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
@@ -272,32 +294,62 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
             const uint32_t sy = ez, sx = ey * ez;
             const uint32_t ex1 = bk.e[0] - 1, ey1 = ey - 1, ez1 = ez - 1;
             const uint32_t lox = bk.lo[0], loy = bk.lo[1], loz = bk.lo[2];
-            for (int k = 0; k < K; ++k) {
-                const uint32_t cx = (r.px >> 16) - lox, cy = (r.py >> 16) - loy, cz = (r.pz >> 16) - loz;
-                const bool inb = cx < ex1 && cy < ey1 && cz < ez1;   // cell and its +1 neighbours are staged
-                const bool pos = it > 0;
-                if (__ballot(pos && !inb) != 0ull) {                 // rare: some lane is outside the brick
-                    // the brick is clipped to the field, so a ray that left the field is outside the brick too
-                    // and simply stops marching; a ray still inside the field forces a new plan
-                    if (__ballot(pos && !inb && in_field(r, bx1, by1, bz1)) != 0ull) { stat_add(p, kStatEarlyExit, 1); break; }
-                }
-                const bool alive = pos && inb;                       // inside the brick => inside the field
-                if (__ballot(alive) == 0ull) break;
-                stat_add(p, kStatLdsWaveSteps, 1);
-                if (alive) {
-                    bool dark = false;
-                    if constexpr (ABSORB) dark = absorb_step(p, r, light);
-                    if (dark) { rem_w = it; it = 0; }
-                    else {
-                        f4 c[8];
-                        gather_lds(seg, __umul24(__umul24(cx, ey) + cy, ez) + cz, sy, sx, c);
-                        if (march_step(r, c, invx, invy, invz, brick_has_w)) { rem_w = it; it = 0; } else --it;
+            // two copies of the loop: in a brick without any positive w (the common case) the opacity test
+            // cannot fire, so that copy carries neither the test nor the rem_w bookkeeping
+            const int Ku = (int)sgpr((uint32_t)K);                       // keep the trip count in an SGPR
+            auto run = [&](auto has_w) {
+                constexpr bool kHasW = decltype(has_w)::value;
+                for (int k = 0; k < Ku; ++k) {
+                    const uint32_t cx = (r.px >> 16) - lox, cy = (r.py >> 16) - loy, cz = (r.pz >> 16) - loz;
+                    const bool inb = cx < ex1 && cy < ey1 && cz < ez1;   // cell and its +1 neighbours are staged
+                    const bool pos = it > 0;
+                    // wave-level tests on the compare masks themselves (scalar ALU): a ballot of a compound
+                    // bool would be materialised through v_cndmask + v_cmp
+                    const uint64_t m_pos = lane_mask(it > 0);
+                    const uint64_t m_inb = lane_mask(cx < ex1) & lane_mask(cy < ey1) & lane_mask(cz < ez1);
+                    if ((m_pos & ~m_inb) != 0ull) {                      // rare: some lane is outside the brick
+                        // the brick is clipped to the field, so a ray that left the field is outside the brick too
+                        // and simply stops marching; a ray still inside the field forces a new plan
+                        if (any_lane(pos && !inb && in_field(r, bx1, by1, bz1))) { stat_add(p, kStatEarlyExit, 1); break; }
+                    }
+                    const bool alive = pos && inb;                       // inside the brick => inside the field
+                    if ((m_pos & m_inb) == 0ull) break;
+                    stat_add(p, kStatLdsWaveSteps, 1);
+                    VRT_TL(++tl_lds);
+                    if (alive) {
+                        bool dark = false;
+                        if constexpr (ABSORB) dark = absorb_step(p, r, light);
+                        if (dark) { rem_w = it; it = 0; }
+                        else {
+                            f4 c[8];
+                            gather_lds(seg, mad24(mad24(cx, ey, cy), ez, cz), sy, sx, c);
+                            if constexpr (kHasW) {
+                                if (march_step(r, c, invx, invy, invz, true)) { rem_w = it; it = 0; } else --it;
+                            } else {
+                                (void)march_step(r, c, invx, invy, invz, false);
+                                --it;
+                            }
+                        }
                     }
                 }
-            }
+            };
+            if (brick_has_w) run(std::true_type{}); else run(std::false_type{});
         }
     }
     if (have) store_ray<DirT>(p, ray, r, rem_w != 0xFFFFFFFFu ? rem_w : it, light);
+#ifdef VRT_SLAB_TIMELINE
+    {
+        const uint32_t done = have ? p.iterations - (rem_w != 0xFFFFFFFFu ? rem_w : it) : 0u;
+        const uint32_t mx = sgpr(__ockl_wfred_max_u32(done));
+        if (p.stats && lane == 0) {
+            unsigned long long *q = p.stats + 64 + 4 * (size_t)(slot >> 6);
+            q[1] = wall_clock64();
+            q[2] = (unsigned long long)tl_lds | ((unsigned long long)tl_dir << 32);
+            q[3] = (unsigned long long)tl_rounds | ((unsigned long long)mx << 32);
+        }
+    }
+#endif
+#undef VRT_TL
 }
 
 template <typename FieldT, typename DirT, int VPL, int OCC, bool ABSORB>

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 #include <stdint.h>
+#include "vrt_march.h"
 
 namespace vrt {
 
@@ -111,17 +112,84 @@ __global__ __launch_bounds__(256) void k_tile_keys(const uint32_t *pos, const Di
     vals[i] = i;
 }
 
+// Longest-first launch order of whole wavefronts.  A launch of W wavefronts on S resident slots runs
+// W/S "rounds"; with caller/tile order the last round starts long marches late and the GPU drains
+// half empty (tools/timeline.py: 26 % of a config-3 launch ran below half occupancy).  Each
+// wavefront (64 consecutive slots of the tile order) gets a work estimate and wavefronts are launched
+// in descending order of it.  Only the launch order changes: slot -> ray stays the tile order, so a
+// wavefront's rays and its brick are the same as without this pass, and so are all results.
+//
+// The estimate is a coarse march of four representative rays per wavefront through the real field:
+// the same update as the march step (.cu:344-348) in plain float arithmetic, but one nearest-voxel
+// sample stands for kCoarse consecutive steps.  (A straight-line distance estimate was tried first:
+// in a strongly refracting field it is off by 2x for the rays that are bent back into the volume,
+// and exactly those wavefronts then started last.)  It only has to rank wavefronts, not to be exact.
+constexpr int kCoarse = 32;          // fine steps per coarse step
+constexpr int kCoarseMaxLoops = 2048;
+
+template <typename FieldT, typename DirT>
+__global__ __launch_bounds__(256) void k_wave_work(const typename FieldTraits<FieldT>::vox *field, const uint32_t *pos,
+                                                   const DirT *dir, const uint32_t *order, uint32_t n, uint32_t Bx,
+                                                   uint32_t By, uint32_t Bz, float invx, float invy, float invz,
+                                                   uint32_t iterations, uint32_t *wkeys, uint32_t *wvals)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t w = t >> 2, nw = (n + 63u) >> 6;
+    if (w >= nw) return;                                   // whole groups of 4 threads leave together
+    const uint32_t rep[4] = {5u, 23u, 40u, 58u};
+    uint32_t slot = w * 64u + rep[t & 3u];
+    slot = slot < n ? slot : n - 1u;
+    const uint32_t i = order ? order[slot] : slot;
+    float px = (float)pos[3 * (size_t)i], py = (float)pos[3 * (size_t)i + 1], pz = (float)pos[3 * (size_t)i + 2];
+    const float dsc = sizeof(DirT) == 4 ? 65536.0f : 256.0f;             // internal direction scale (.cu:328-331)
+    float dx = (float)dir[3 * (size_t)i] * dsc, dy = (float)dir[3 * (size_t)i + 1] * dsc, dz = (float)dir[3 * (size_t)i + 2] * dsc;
+    const float hx = (float)(Bx - 1) * 65536.0f, hy = (float)(By - 1) * 65536.0f, hz = (float)(Bz - 1) * 65536.0f;
+    const uint32_t cap = iterations / kCoarse + 1u;
+    const uint32_t loops_max = cap < (uint32_t)kCoarseMaxLoops ? cap : (uint32_t)kCoarseMaxLoops;
+    const float m = (float)kCoarse;
+    bool alive = true;
+    uint32_t est = 0;                                     // coarse steps until the last representative stops
+    for (uint32_t loops = 0; loops < loops_max; ++loops) {
+        alive = alive && px >= 0.0f && py >= 0.0f && pz >= 0.0f && px < hx && py < hy && pz < hz;   // false on NaN
+        if (!alive) break;
+        const uint32_t cx = (uint32_t)(px * (1.0f / 65536.0f)), cy = (uint32_t)(py * (1.0f / 65536.0f)), cz = (uint32_t)(pz * (1.0f / 65536.0f));
+        f4 g;
+        cvt_vox(field[((size_t)cx * By + cy) * Bz + cz], g);
+        if (g.w > 0.0f) break;
+        dx = fmaf(g.x * m, invx, dx);
+        dy = fmaf(g.y * m, invy, dy);
+        dz = fmaf(g.z * m, invz, dz);
+        const float il = m * 0x42000000p0f / (dx * dx + dy * dy + dz * dz);
+        px = fmaf(dx * invx, il, px);
+        py = fmaf(dy * invy, il, py);
+        pz = fmaf(dz * invz, il, pz);
+        ++est;
+    }
+    // a wavefront marches until its last ray stops: the largest of the four estimates.  (Weighting steps the
+    // planner would have to gather from global memory by 1.5 was tried and ordered no better.)
+    est = max(est, (uint32_t)__shfl_xor((int)est, 1));
+    est = max(est, (uint32_t)__shfl_xor((int)est, 2));
+    if ((t & 3u) == 0) {
+        wkeys[w] = 0xFFFFFFFFu - est;                                      // ascending sort = longest first
+        wvals[w] = w;
+    }
+}
+
 // grow-only device buffer interface expected from the caller (see DevBuf in vrt_engine.hip)
 template <typename Buf>
 hipError_t build_tile_order(const uint32_t *d_pos, const void *d_dir, int dir_is_i16, uint32_t n,
                             uint32_t Bx, uint32_t By, uint32_t Bz, int lpt, Buf &keys,
                             Buf &keys_alt, Buf &vals, Buf &vals_alt, Buf &tmp, Buf &bounds, hipStream_t s,
-                            const uint32_t **order_out)
+                            const uint32_t **order_out, int wave_lpt = 0, uint32_t iterations = 0,
+                            const uint32_t **wave_order_out = nullptr, const void *field = nullptr, int field_is_i16 = 0,
+                            const float *inv = nullptr)
 {
     hipError_t e;
-    if ((e = keys.reserve((size_t)n * 4)) != hipSuccess) return e;
+    const uint32_t nw = (n + 63u) >> 6;
+    const size_t kbytes = ((size_t)n > 2 * (size_t)nw ? (size_t)n : 2 * (size_t)nw) * 4;   // keys/vals are reused for the wavefront sort
+    if ((e = keys.reserve(kbytes)) != hipSuccess) return e;
     if ((e = keys_alt.reserve((size_t)n * 4)) != hipSuccess) return e;
-    if ((e = vals.reserve((size_t)n * 4)) != hipSuccess) return e;
+    if ((e = vals.reserve(kbytes)) != hipSuccess) return e;
     if ((e = vals_alt.reserve((size_t)n * 4)) != hipSuccess) return e;
     if ((e = bounds.reserve(sizeof(RayBounds))) != hipSuccess) return e;
     RayBounds *rb = (RayBounds *)bounds.p;
@@ -141,6 +209,27 @@ hipError_t build_tile_order(const uint32_t *d_pos, const void *d_dir, int dir_is
                                   (const uint32_t *)vals.p, (uint32_t *)vals_alt.p, n, 0, lpt ? 32 : 29, s);
     if (e != hipSuccess) return e;
     *order_out = (const uint32_t *)vals_alt.p;
+    if (wave_lpt && wave_order_out && field && inv && nw > 1) {
+        // the ray sort's input buffers are free again: [0, nw) = wavefront keys / ids, [nw, 2 nw) = sorted
+        uint32_t *wk = (uint32_t *)keys.p, *wv = (uint32_t *)vals.p;
+        const uint32_t *ord = (const uint32_t *)vals_alt.p;
+        const unsigned wgrid = (4u * nw + 255u) / 256u;
+        using vf = const FieldTraits<float>::vox *;
+        using vi = const FieldTraits<int16_t>::vox *;
+#define VRT_WW(FT, DT, FP) k_wave_work<FT, DT><<<wgrid, 256, 0, s>>>((FP)field, d_pos, (const DT *)d_dir, ord, n, Bx, By, Bz, \
+                                                                     inv[0], inv[1], inv[2], iterations, wk, wv)
+        if (field_is_i16) { if (dir_is_i16) VRT_WW(int16_t, int16_t, vi); else VRT_WW(int16_t, float, vi); }
+        else              { if (dir_is_i16) VRT_WW(float, int16_t, vf);   else VRT_WW(float, float, vf); }
+#undef VRT_WW
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        size_t wtmp = 0;
+        e = rocprim::radix_sort_pairs(nullptr, wtmp, (const uint32_t *)wk, wk + nw, (const uint32_t *)wv, wv + nw, nw, 0, 32, s);
+        if (e != hipSuccess) return e;
+        if (wtmp > tmp_bytes && (e = tmp.reserve(wtmp)) != hipSuccess) return e;
+        e = rocprim::radix_sort_pairs(tmp.p, wtmp, (const uint32_t *)wk, wk + nw, (const uint32_t *)wv, wv + nw, nw, 0, 32, s);
+        if (e != hipSuccess) return e;
+        *wave_order_out = wv + nw;
+    }
     return hipSuccess;
 }
 
