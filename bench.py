@@ -180,6 +180,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
     ap.add_argument("--kernel", default="auto", choices=["auto", "direct", "slab"])
+    ap.add_argument("--schedule", type=int, default=0, help="slab kernel scheduling: 0 auto, 1 static, 2 persistent wavefronts")
     ap.add_argument("--sort", type=int, default=0, help="0 auto, 1 force tile order, -1 caller order")
     ap.add_argument("--lds-bytes", type=int, default=0)
     ap.add_argument("--iterations", type=int, default=100000)
@@ -249,7 +250,7 @@ def main():
     counts = [n] * world
     inv = [1.0, 1.0, 1.0]
     kern = {"auto": capi.KERNEL_AUTO, "direct": capi.KERNEL_DIRECT, "slab": capi.KERNEL_SLAB}[args.kernel]
-    opts = capi.default_options(kernel=kern, sort_rays=args.sort, slab_lds_bytes=args.lds_bytes)
+    opts = capi.default_options(kernel=kern, sort_rays=args.sort, slab_lds_bytes=args.lds_bytes, schedule=args.schedule)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():

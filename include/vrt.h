@@ -66,7 +66,9 @@ typedef struct vrt_options {
                               * remaining_light returns the brightness.  Must be set at vrt_create (keeps the
                               * translucency resident) AND at vrt_trace.  PARITY UNPINNED: no reference build
                               * can execute this branch; the checker is oracle/vrt_oracle.c's restatement. */
-    int32_t  reserved[3];
+    int32_t  schedule;       /* extension: slab-kernel scheduling. 0 = auto, 1 = static (one wavefront per group of 64
+                                rays, hardware dispatch order), 2 = persistent wavefronts drawing groups from a counter */
+    int32_t  reserved[2];
 } vrt_options;
 
 #define VRT_KERNEL_AUTO   0

@@ -30,8 +30,8 @@ def _assert_same(got, want, keys=KEYS, ctx=""):
                 ctx, k, bad.size, got[k].size, bad[0], got[k].reshape(-1)[bad[0]], want[k].reshape(-1)[bad[0]]))
 
 
-def _opts(kernel, sort=0):
-    return capi.default_options(kernel=kernel, sort_rays=sort)
+def _opts(kernel, sort=0, schedule=0):
+    return capi.default_options(kernel=kernel, sort_rays=sort, schedule=schedule)
 
 
 def _load(golden_dir, name):
@@ -304,3 +304,31 @@ def test_short_division_is_exact_for_every_admitted_float():
     bad, admitted = capi.selftest_ilen2(0)
     assert bad == 0
     assert admitted == (251 - 32) * (1 << 23)          # positive d with biased exponent 32..250, nothing else
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fdt", [np.float32, np.int16])
+@pytest.mark.parametrize("ddt", [np.float32, np.int16])
+def test_persistent_schedule(fdt, ddt):
+    """schedule = 2: a grid of resident wavefronts, each drawing groups of 64 rays from a counter until it runs
+    out (the auto mode for launches larger than the GPU holds).  Results must not depend on which wavefront
+    marches which group: coherent + incoherent rays, ragged last group, NaN / inf directions, all sort modes,
+    more groups than resident wavefronts cannot be forced at this size, so the counter path is what is tested."""
+    N = 48
+    bounds, dx, dy, dz, tc = W.seam_field(N, fdt, opaque_radius=5.0)
+    field = oracle.port.interleave(dx, dy, dz, tc)
+    sp1, sd1 = W.perspective_rays(N, 75, dir_dtype=ddt)
+    sp2, sd2 = W.random_rays(N, 3001, seed=5, vol_seed=1234)
+    if ddt == np.int16:
+        sd2 = np.clip(np.round(sd2 * 256.0), -32768, 32767).astype(np.int16)
+    sp, sd = np.concatenate([sp1, sp2]), np.concatenate([sd1, sd2])
+    if ddt == np.float32:
+        sd.reshape(-1, 3)[5::173, 1] = np.nan
+        sd.reshape(-1, 3)[7::191, 0] = np.inf
+        sd.reshape(-1, 3)[11::197] = 0.0
+    for inv, cap in (([1, 1, 1], 100000), ([0.5, 1, 2], 300)):
+        want = oracle.port.trace(field, bounds, sp, sd, inv, cap)
+        with capi.Engine.from_host(bounds, [dx, dy, dz], tc) as eng:
+            for sort in (-1, 1, 3):
+                got = eng.trace(sp, sd, inv, cap, options=_opts(capi.KERNEL_SLAB, sort, schedule=2))
+                _assert_same(got, want, ctx="inv=%s cap=%d sort=%d" % (inv, cap, sort))

@@ -37,6 +37,7 @@ struct MarchParams {
     unsigned long long *stats; // optional debug counters (nullptr in production), see vrt_slab.h
     const uint32_t *transl;   // ABSORB kernels only: translucency per field voxel (opt-in mode, .cu:337-341)
     uint32_t min_brightness;  // ABSORB kernels only
+    uint32_t *group_counter;  // persistent slab kernel only: next group of 64 slots to start (zeroed per launch)
     uint32_t out_pos_bias;    // added to end_pos / path on output: 0 at the seam, 0x10000 for the scene
                               // layer's "+0x10000" epilogue (image_util.cpp:770-771)
 };

@@ -57,6 +57,23 @@ __device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c)
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
     return d;
 }
+// The persistent variant's group counter is bumped as straight-line, wave-uniform code: the atomic executes
+// in lane 0 only by narrowing EXEC inside the asm block (restored before it ends).  An `if (lane == 0)`
+// region around it made the compiler carry the divergence into the march that follows (lane 0 then
+// marched alone and staged only its own share of the brick) -- wave-level code must not sit behind a
+// divergent branch.
+__device__ __forceinline__ uint32_t lane0_atomic_add(uint32_t *ptr, uint32_t v)
+{
+    uint32_t old;
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %1, exec\n\t"
+                 "s_mov_b64 exec, 1\n\t"
+                 "global_atomic_add %0, %2, %3, off sc0\n\t"
+                 "s_waitcnt vmcnt(0)\n\t"
+                 "s_mov_b64 exec, %1"
+                 : "=&v"(old), "=&s"(saved) : "v"(ptr), "v"(v) : "memory");
+    return __builtin_amdgcn_readfirstlane(old);
+}
 __device__ __forceinline__ uint64_t lane_mask(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 
 // debug counters (MarchParams::stats != nullptr): per-wave events, added by lane 0
@@ -141,7 +158,7 @@ __device__ __forceinline__ void gather_lds(const LV *seg, uint32_t base, uint32_
 
 // VPL = voxels staged per lane at most; the wave's LDS segment holds 64*VPL fp32 voxels (16 B each).
 // OCC = waves per SIMD the register allocator must allow (launch-bounds second argument).
-template <typename FieldT, typename DirT, int VPL, int OCC, bool ABSORB>
+template <typename FieldT, typename DirT, int VPL, int OCC, bool ABSORB, bool PERSIST = false>
 __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(const MarchParams p)
 {
     using vox = typename FieldTraits<FieldT>::vox;
@@ -152,35 +169,31 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
     lvox *seg = (lvox *)smem + (size_t)wave * kCap;
 
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t slot = launch_slot(p);
-    const bool have = slot < p.nrays;
-    const uint32_t ray = have ? (p.order ? p.order[slot] : slot) : 0u;
-    Ray r;
-    r.px = r.py = r.pz = 0; r.dx = r.dy = r.dz = 1.0f;
-    if (have) load_ray<DirT>(p, ray, r);
     const vox *f = (const vox *)p.field;
     const uint32_t B[3] = {p.Bx, p.By, p.Bz};
     const uint32_t bx1 = (p.Bx - 1) & 0xFFFFu, by1 = (p.By - 1) & 0xFFFFu, bz1 = (p.Bz - 1) & 0xFFFFu;
     const float invx = p.invx, invy = p.invy, invz = p.invz;
 
-    // `it` is the reference's remaining-iterations counter (.cu:333-351): it drops by one per
+    // Per-ray state.  `it` is the reference's remaining-iterations counter (.cu:333-351): it drops by one per
     // completed step and the ray stops at it == 0, on leaving the field, or on w > 0; the value at
     // that moment is raydata._iterations.  A ray stopped by the w > 0 test parks that value in
     // `rem_w` and zeroes `it`, so "it > 0 and inside the field" is the only liveness predicate.
+    Ray r;
+    uint32_t it, rem_w, light;                          // light: brightness, ABSORB only (.cu:332)
+    uint32_t slot, ray;
+    bool have;
 #ifdef VRT_SLAB_TIMELINE   // development builds: 4 words per wavefront after the 64 counters (tools/timeline.py)
-    if (p.stats && lane == 0) p.stats[64 + 4 * (size_t)(slot >> 6)] = wall_clock64();
     uint32_t tl_lds = 0, tl_dir = 0, tl_rounds = 0;
 #define VRT_TL(x) (x)
 #else
 #define VRT_TL(x) ((void)0)
 #endif
-    uint32_t it = have ? p.iterations - 1 : 0u;
-    uint32_t rem_w = 0xFFFFFFFFu;
-    uint32_t light = 0xFFFFFFFFu;                       // brightness, ABSORB only (.cu:332)
 
+    // march(): advances the wavefront's rays until all of them have stopped
+    auto march = [&]() {
     for (;;) {
         const bool live = it > 0 && in_field(r, bx1, by1, bz1);
-        if (!any_lane(live)) break;              // wave early-out: every lane has terminated
+        if (!any_lane(live)) return;             // wave early-out: every lane has terminated
 
         // ---- plan -------------------------------------------------------------------------
         int32_t s[3];
@@ -316,7 +329,7 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                     if ((m_pos & m_inb) == 0ull) break;
                     stat_add(p, kStatLdsWaveSteps, 1);
                     VRT_TL(++tl_lds);
-                    if (alive) {
+                        if (alive) {
                         bool dark = false;
                         if constexpr (ABSORB) dark = absorb_step(p, r, light);
                         if (dark) { rem_w = it; it = 0; }
@@ -336,29 +349,72 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
             if (brick_has_w) run(std::true_type{}); else run(std::false_type{});
         }
     }
-    if (have) store_ray<DirT>(p, ray, r, rem_w != 0xFFFFFFFFu ? rem_w : it, light);
+    };  // march
+
+    auto begin_group = [&](uint32_t first_slot) {        // fill_struct (.cu:468-487): fresh rays from the caller's arrays
+        slot = first_slot + lane;
+        have = slot < p.nrays;
+        ray = have ? (p.order ? p.order[slot] : slot) : 0u;
+        r.px = r.py = r.pz = 0; r.dx = r.dy = r.dz = 1.0f;
+        if (have) load_ray<DirT>(p, ray, r);
+        it = have ? p.iterations - 1 : 0u;
+        rem_w = 0xFFFFFFFFu;
+        light = 0xFFFFFFFFu;
+    };
+
+    if constexpr (!PERSIST) {
+        // one wavefront per group of 64 slots; the hardware dispatcher hands out groups in launch order
+        begin_group(launch_slot(p) & ~63u);
 #ifdef VRT_SLAB_TIMELINE
-    {
-        const uint32_t done = have ? p.iterations - (rem_w != 0xFFFFFFFFu ? rem_w : it) : 0u;
-        const uint32_t mx = sgpr(__ockl_wfred_max_u32(done));
-        if (p.stats && lane == 0) {
-            unsigned long long *q = p.stats + 64 + 4 * (size_t)(slot >> 6);
-            q[1] = wall_clock64();
-            q[2] = (unsigned long long)tl_lds | ((unsigned long long)tl_dir << 32);
-            q[3] = (unsigned long long)tl_rounds | ((unsigned long long)mx << 32);
+        if (p.stats && lane == 0) p.stats[64 + 4 * (size_t)(slot >> 6)] = wall_clock64();
+#endif
+        march();
+        if (have) store_ray<DirT>(p, ray, r, rem_w != 0xFFFFFFFFu ? rem_w : it, light);
+#ifdef VRT_SLAB_TIMELINE
+        {
+            const uint32_t done = have ? p.iterations - (rem_w != 0xFFFFFFFFu ? rem_w : it) : 0u;
+            const uint32_t mx = sgpr(__ockl_wfred_max_u32(done));
+            if (p.stats && lane == 0) {
+                unsigned long long *q = p.stats + 64 + 4 * (size_t)(slot >> 6);
+                q[1] = wall_clock64();
+                q[2] = (unsigned long long)tl_lds | ((unsigned long long)tl_dir << 32);
+                q[3] = (unsigned long long)tl_rounds | ((unsigned long long)mx << 32);
+            }
+        }
+#endif
+    } else {
+        // Persistent wavefronts: the grid is what the GPU holds at once and every wavefront draws the next
+        // group from a counter as soon as it has finished one -- no slot idles until the other three
+        // wavefronts of a workgroup are done, and the launch order (longest first) is followed exactly.
+        // Every wavefront leaves as soon as the counter runs out; nobody waits for anybody.
+        const uint32_t ngroups = (p.nrays + 63u) >> 6;
+        for (;;) {
+            const uint32_t fr = lane0_atomic_add(p.group_counter, 1u);
+            if (fr >= ngroups) break;
+            begin_group((p.wave_order ? sgpr(p.wave_order[fr]) : fr) * 64u);
+            march();
+            if (have) store_ray<DirT>(p, ray, r, rem_w != 0xFFFFFFFFu ? rem_w : it, light);
         }
     }
-#endif
 #undef VRT_TL
 }
 
 template <typename FieldT, typename DirT, int VPL, int OCC, bool ABSORB>
-hipError_t launch_slab_vpl(const MarchParams &p, hipStream_t s)
+hipError_t launch_slab_vpl(const MarchParams &p, int num_cu, hipStream_t s)
 {
     const unsigned threads = 64 * kSlabWavesPerBlock;
-    const unsigned grid = (p.nrays + threads - 1) / threads;
+    const unsigned groups_blocks = (p.nrays + threads - 1) / threads;
     const size_t lds = sizeof(typename LdsVox<FieldT>::type) * 64 * VPL * kSlabWavesPerBlock;
-    k_march_slab<FieldT, DirT, VPL, OCC, ABSORB><<<grid, threads, lds, s>>>(p);
+    constexpr size_t seg_bytes = sizeof(typename LdsVox<FieldT>::type) * 64 * VPL;
+    constexpr bool kHasPersist = seg_bytes == 6144 || seg_bytes == 8192;    // launch_slab sends persistent launches only here
+    if constexpr (kHasPersist) if (p.group_counter) {
+        // persistent grid: the wavefronts the GPU holds at once (OCC per SIMD = OCC blocks of 4 wavefronts per CU)
+        const unsigned resident = (unsigned)(num_cu > 0 ? num_cu : 256) * (unsigned)OCC;
+        const unsigned grid = groups_blocks < resident ? groups_blocks : resident;
+        k_march_slab<FieldT, DirT, VPL, OCC, ABSORB, true><<<grid, threads, lds, s>>>(p);
+        return hipGetLastError();
+    }
+    k_march_slab<FieldT, DirT, VPL, OCC, ABSORB, false><<<groups_blocks, threads, lds, s>>>(p);
     return hipGetLastError();
 }
 
@@ -366,15 +422,15 @@ hipError_t launch_slab_vpl(const MarchParams &p, hipStream_t s)
 // register budget (waves per SIMD the allocator must allow) both follow from the byte size:
 // 160 KiB LDS / CU and 512 VGPRs per SIMD lane give 8 waves/SIMD at <= 5 KiB, 6 at 6 KiB, 5 at 8 KiB ...
 template <typename FieldT, typename DirT, int BYTES, int OCC, bool ABSORB = false>
-hipError_t launch_slab_bytes(const MarchParams &p, hipStream_t s)
+hipError_t launch_slab_bytes(const MarchParams &p, int num_cu, hipStream_t s)
 {
-    return launch_slab_vpl<FieldT, DirT, BYTES / (64 * (int)sizeof(typename LdsVox<FieldT>::type)), OCC, ABSORB>(p, s);
+    return launch_slab_vpl<FieldT, DirT, BYTES / (64 * (int)sizeof(typename LdsVox<FieldT>::type)), OCC, ABSORB>(p, num_cu, s);
 }
 
 template <typename FieldT, typename DirT>
 hipError_t launch_slab(MarchParams p, bool /*path*/, int num_cu, hipStream_t s)
 {
-    // default: 6 KiB (26 waves/CU) measured best when the launch oversubscribes the GPU (configs 3-5); a
+    // default: 6 KiB (24 waves/CU) measured best when the launch oversubscribes the GPU (configs 3-5); a
     // launch with fewer wavefronts than LDS slots loses nothing to a bigger segment and gains longer rounds
     uint32_t want = p.slab_lds_bytes;
     if (want == 0) {
@@ -382,15 +438,19 @@ hipError_t launch_slab(MarchParams p, bool /*path*/, int num_cu, hipStream_t s)
         want = waves_per_cu <= 20 ? 8192u : 6144u;
     }
     if (p.transl) {                                    // opt-in absorption mode: the two default sizes only
-        if (want <= 6144) return launch_slab_bytes<FieldT, DirT, 6144, 6, true>(p, s);
-        return launch_slab_bytes<FieldT, DirT, 8192, 5, true>(p, s);
+        if (want <= 6144) return launch_slab_bytes<FieldT, DirT, 6144, 6, true>(p, num_cu, s);
+        return launch_slab_bytes<FieldT, DirT, 8192, 5, true>(p, num_cu, s);
     }
-    if (want <= 4096) return launch_slab_bytes<FieldT, DirT, 4096, 8>(p, s);
-    if (want <= 5120) return launch_slab_bytes<FieldT, DirT, 5120, 7>(p, s);
-    if (want <= 6144) return launch_slab_bytes<FieldT, DirT, 6144, 6>(p, s);
-    if (want <= 8192) return launch_slab_bytes<FieldT, DirT, 8192, 5>(p, s);
-    if (want <= 12288) return launch_slab_bytes<FieldT, DirT, 12288, 3>(p, s);
-    return launch_slab_bytes<FieldT, DirT, 16384, 2>(p, s);
+    if (p.group_counter || want == 6144 || want == 8192) { // the persistent variant exists for the two default sizes
+        if (want <= 6144) return launch_slab_bytes<FieldT, DirT, 6144, 6>(p, num_cu, s);
+        return launch_slab_bytes<FieldT, DirT, 8192, 5>(p, num_cu, s);
+    }
+    if (want <= 4096) return launch_slab_bytes<FieldT, DirT, 4096, 8>(p, num_cu, s);
+    if (want <= 5120) return launch_slab_bytes<FieldT, DirT, 5120, 7>(p, num_cu, s);
+    if (want <= 6144) return launch_slab_bytes<FieldT, DirT, 6144, 6>(p, num_cu, s);
+    if (want <= 8192) return launch_slab_bytes<FieldT, DirT, 8192, 5>(p, num_cu, s);
+    if (want <= 12288) return launch_slab_bytes<FieldT, DirT, 12288, 3>(p, num_cu, s);
+    return launch_slab_bytes<FieldT, DirT, 16384, 2>(p, num_cu, s);
 }
 
 }  // namespace vrt
