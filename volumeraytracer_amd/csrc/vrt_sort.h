@@ -31,6 +31,9 @@ __global__ void k_bounds_init(RayBounds *b)
 
 __global__ __launch_bounds__(256) void k_ray_bounds(const uint32_t *pos, uint32_t n, RayBounds *b)
 {
+    // one atomic per block and component: with one per wavefront, 4096 wavefronts hammering six addresses
+    // took 280 us for 12 MB of input (the atomics serialise)
+    __shared__ uint32_t s_lo[4][3], s_hi[4][3];
     uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 #pragma unroll
@@ -47,7 +50,15 @@ __global__ __launch_bounds__(256) void k_ray_bounds(const uint32_t *pos, uint32_
             lo[d] = a < lo[d] ? a : lo[d];
             hi[d] = c > hi[d] ? c : hi[d];
         }
-        if ((threadIdx.x & 63u) == 0) { atomicMin(&b->lo[d], lo[d]); atomicMax(&b->hi[d], hi[d]); }
+        if ((threadIdx.x & 63u) == 0) { s_lo[threadIdx.x >> 6][d] = lo[d]; s_hi[threadIdx.x >> 6][d] = hi[d]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int d = threadIdx.x;
+        uint32_t l = s_lo[0][d], h = s_hi[0][d];
+        for (int w = 1; w < 4; ++w) { l = s_lo[w][d] < l ? s_lo[w][d] : l; h = s_hi[w][d] > h ? s_hi[w][d] : h; }
+        atomicMin(&b->lo[d], l);
+        atomicMax(&b->hi[d], h);
     }
 }
 
@@ -124,7 +135,10 @@ __global__ __launch_bounds__(256) void k_tile_keys(const uint32_t *pos, const Di
 // sample stands for kCoarse consecutive steps.  (A straight-line distance estimate was tried first:
 // in a strongly refracting field it is off by 2x for the rays that are bent back into the volume,
 // and exactly those wavefronts then started last.)  It only has to rank wavefronts, not to be exact.
-constexpr int kCoarse = 32;          // fine steps per coarse step
+#ifndef VRT_COARSE
+#define VRT_COARSE 64
+#endif
+constexpr int kCoarse = VRT_COARSE;  // fine steps per coarse step
 constexpr int kCoarseMaxLoops = 2048;
 
 template <typename FieldT, typename DirT>
@@ -194,7 +208,7 @@ hipError_t build_tile_order(const uint32_t *d_pos, const void *d_dir, int dir_is
     if ((e = bounds.reserve(sizeof(RayBounds))) != hipSuccess) return e;
     RayBounds *rb = (RayBounds *)bounds.p;
     k_bounds_init<<<1, 64, 0, s>>>(rb);
-    const unsigned rgrid = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    const unsigned rgrid = (unsigned)((n + 255) / 256 < 512 ? (n + 255) / 256 : 512);
     k_ray_bounds<<<rgrid, 256, 0, s>>>(d_pos, n, rb);
     const unsigned grid = (n + 255) / 256;
     if (dir_is_i16) k_tile_keys<int16_t><<<grid, 256, 0, s>>>(d_pos, (const int16_t *)d_dir, n, rb, Bx, By, Bz, lpt, (uint32_t *)keys.p, (uint32_t *)vals.p);
