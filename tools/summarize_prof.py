@@ -12,7 +12,7 @@ import json
 import os
 import sys
 
-KEEP = ("k_march", "k_tile_keys", "k_interleave", "radix", "onesweep", "rocprim")
+KEEP = ("k_march", "k_tile_keys", "k_interleave", "radix", "onesweep", "rocprim", "k_wave_work", "k_ray_bounds")
 
 
 def short(name):

@@ -430,12 +430,17 @@ hipError_t launch_slab_bytes(const MarchParams &p, int num_cu, hipStream_t s)
 template <typename FieldT, typename DirT>
 hipError_t launch_slab(MarchParams p, bool /*path*/, int num_cu, hipStream_t s)
 {
-    // default: 6 KiB (24 waves/CU) measured best when the launch oversubscribes the GPU (configs 3-5); a
-    // launch with fewer wavefronts than LDS slots loses nothing to a bigger segment and gains longer rounds
+    // default: 6 KiB (24 waves/CU) measured best when the launch oversubscribes the GPU (configs 3, 4); a
+    // launch with fewer wavefronts than LDS slots loses nothing to a bigger segment and gains longer rounds,
+    // and so do sparse ray sets: at one ray per voxel column or fewer a 64-ray tile is >= 8 x 8 voxels wide,
+    // the 6 KiB brick is only a few voxels deep, and 8 KiB measured 5 % faster (config 5: 18.3 -> 17.4 ms;
+    // config 4 with 16 rays per column: 29.0 -> 32.1 ms, so dense sets stay at 6 KiB)
     uint32_t want = p.slab_lds_bytes;
     if (want == 0) {
         const uint64_t waves_per_cu = ((uint64_t)p.nrays + 63) / 64 / (uint64_t)(num_cu > 0 ? num_cu : 256);
-        want = waves_per_cu <= 20 ? 8192u : 6144u;
+        const uint64_t bmax = p.Bx > p.By ? (p.Bx > p.Bz ? p.Bx : p.Bz) : (p.By > p.Bz ? p.By : p.Bz);
+        const bool sparse = 2 * (uint64_t)p.nrays <= 3 * bmax * bmax;          // <= 1.5 rays per voxel of the largest face
+        want = (waves_per_cu <= 20 || sparse) ? 8192u : 6144u;
     }
     if (p.transl) {                                    // opt-in absorption mode: the two default sizes only
         if (want <= 6144) return launch_slab_bytes<FieldT, DirT, 6144, 6, true>(p, num_cu, s);

@@ -140,6 +140,9 @@ __global__ __launch_bounds__(256) void k_tile_keys(const uint32_t *pos, const Di
 #endif
 constexpr int kCoarse = VRT_COARSE;  // fine steps per coarse step
 constexpr int kCoarseMaxLoops = 2048;
+#ifndef VRT_LPT_SHIFT
+#define VRT_LPT_SHIFT 0
+#endif
 
 template <typename FieldT, typename DirT>
 __global__ __launch_bounds__(256) void k_wave_work(const typename FieldTraits<FieldT>::vox *field, const uint32_t *pos,
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(256) void k_wave_work(const typename FieldTraits<Fi
     est = max(est, (uint32_t)__shfl_xor((int)est, 1));
     est = max(est, (uint32_t)__shfl_xor((int)est, 2));
     if ((t & 3u) == 0) {
-        wkeys[w] = 0xFFFFFFFFu - est;                                      // ascending sort = longest first
+        wkeys[w] = 0xFFFFFFFFu - (est >> VRT_LPT_SHIFT);                   // ascending sort = longest first
         wvals[w] = w;
     }
 }
