@@ -37,6 +37,11 @@ def test_absorption_vs_restatement(fdt, kernel):
             got = eng.trace(sp, sd, [1, 1, 1], 100000, min_brightness=minb, options=on)
             for k in KEYS:
                 assert _same(got[k], want[k]), (k, hex(minb))
+            if kernel == capi.KERNEL_SLAB:              # persistent schedule + longest-first order carry the brightness too
+                got = eng.trace(sp, sd, [1, 1, 1], 100000, min_brightness=minb,
+                                options=capi.default_options(absorption=1, kernel=kernel, schedule=2, sort_rays=3))
+                for k in KEYS:
+                    assert _same(got[k], want[k]), (k, hex(minb), "persistent")
         # brightness only ever decreases, and a higher cut-off never lets a ray go further
         a = eng.trace(sp, sd, [1, 1, 1], 100000, min_brightness=0x10000000, options=on)
         b = eng.trace(sp, sd, [1, 1, 1], 100000, min_brightness=0x80000000, options=on)
