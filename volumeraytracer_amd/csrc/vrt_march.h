@@ -245,18 +245,24 @@ __device__ __forceinline__ uint32_t launch_slot(const MarchParams &p)
 // =========================================================================================
 
 template <typename FieldT>
-__device__ __forceinline__ void gather_global(const typename FieldTraits<FieldT>::vox *f, const Ray &r,
-                                              uint32_t By, uint32_t Bz, f4 (&c)[8])
+__device__ __forceinline__ void gather_global_raw(const typename FieldTraits<FieldT>::vox *f, const Ray &r, uint32_t By,
+                                                  uint32_t Bz, typename FieldTraits<FieldT>::vox (&v)[8])
 {
-    using vox = typename FieldTraits<FieldT>::vox;
     const size_t idx = ((size_t)((r.px >> 16) * By + (r.py >> 16))) * Bz + (r.pz >> 16);
-    const vox *b = f + idx;
+    const typename FieldTraits<FieldT>::vox *b = f + idx;
     const size_t sy = Bz, sx = (size_t)By * Bz;
-    vox v[8];
     v[0] = b[0];       v[1] = b[1];
     v[2] = b[sy];      v[3] = b[sy + 1];
     v[4] = b[sx];      v[5] = b[sx + 1];
     v[6] = b[sx + sy]; v[7] = b[sx + sy + 1];
+}
+
+template <typename FieldT>
+__device__ __forceinline__ void gather_global(const typename FieldTraits<FieldT>::vox *f, const Ray &r,
+                                              uint32_t By, uint32_t Bz, f4 (&c)[8])
+{
+    typename FieldTraits<FieldT>::vox v[8];
+    gather_global_raw<FieldT>(f, r, By, Bz, v);
 #pragma unroll
     for (int k = 0; k < 8; ++k) cvt_vox(v[k], c[k]);
 }

@@ -33,6 +33,12 @@ extern "C" __device__ int __ockl_wfred_max_i32(int);
 namespace vrt {
 
 constexpr int kSlabWavesPerBlock = 4;
+// A wavefront in global-gather mode is latency-bound (tools/timeline.py: 2.6 us per step against 0.65 us from LDS,
+// and the launch ends with exactly these wavefronts): its few instructions go first.  Measured -2.8 % on config 3,
+// +-1 % on configs 4 and 5; priority for the first-launched groups as well gave nothing more.
+#ifndef VRT_PRIO_DIRECT
+#define VRT_PRIO_DIRECT 3
+#endif
 #ifndef VRT_SLAB_MAXK
 #define VRT_SLAB_MAXK 192
 #endif
@@ -246,6 +252,17 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
             stat_add(p, 11, (unsigned long long)__popcll(__ballot(live)));                    // live lanes at fallback
             stat_add(p, 12, (unsigned long long)(p.iterations - 1 - sgpr(__ockl_wfred_max_u32(live ? it : 0u))));  // steps done (min over lanes)
 #endif
+#if VRT_PRIO_DIRECT
+            __builtin_amdgcn_s_setprio(VRT_PRIO_DIRECT);
+#endif
+            // A ray advances about a quarter voxel per step, so it reads the same eight corners for several
+            // steps in a row.  With an int16 field the raw corners (16 registers) stay in registers and only
+            // lanes that entered a new cell gather again (a quarter of the lanes per step -- the vector L1 / TA
+            // path is what bounds this mode): -6 % on config 5.  An fp32 field needs 32 registers for that,
+            // which spills at 6 waves/SIMD (+27 % on config 3), so it gathers every step.
+            constexpr bool kKeepCorners = sizeof(FieldT) == 2;   // (fp32 at 5 waves/SIMD and 96 registers still spills: 9.5 vs 9.0 ms)
+            vox kept[kKeepCorners ? 8 : 1];
+            uint32_t have_xy = 0xFFFFFFFFu, have_z = 0xFFFFFFFFu;   // cell of the corners in kept[]: (x | y << 16, z); none yet
             for (int k = 0; k < kSlabDirectSteps; ++k) {
                 const bool alive = it > 0 && in_field(r, bx1, by1, bz1);
                 if (!any_lane(alive)) break;
@@ -257,11 +274,25 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                     if (dark) { rem_w = it; it = 0; }
                     else {
                         f4 c[8];
-                        gather_global<FieldT>(f, r, p.By, p.Bz, c);
+                        if constexpr (kKeepCorners) {
+                            const uint32_t xy = (r.px >> 16) | (r.py & 0xFFFF0000u), z = r.pz >> 16;
+                            if (xy != have_xy || z != have_z) {
+                                gather_global_raw<FieldT>(f, r, p.By, p.Bz, kept);
+                                have_xy = xy;
+                                have_z = z;
+                            }
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) cvt_vox(kept[q], c[q]);
+                        } else {
+                            gather_global<FieldT>(f, r, p.By, p.Bz, c);
+                        }
                         if (march_step(r, c, invx, invy, invz)) { rem_w = it; it = 0; } else --it;
                     }
                 }
             }
+#if VRT_PRIO_DIRECT
+            __builtin_amdgcn_s_setprio(0);
+#endif
             continue;
         }
 
@@ -392,8 +423,24 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
             const uint32_t fr = lane0_atomic_add(p.group_counter, 1u);
             if (fr >= ngroups) break;
             begin_group((p.wave_order ? sgpr(p.wave_order[fr]) : fr) * 64u);
+#ifdef VRT_SLAB_TIMELINE
+            if (p.stats && lane == 0) p.stats[64 + 4 * (size_t)(slot >> 6)] = wall_clock64();
+            tl_lds = tl_dir = tl_rounds = 0;
+#endif
             march();
             if (have) store_ray<DirT>(p, ray, r, rem_w != 0xFFFFFFFFu ? rem_w : it, light);
+#ifdef VRT_SLAB_TIMELINE
+            {
+                const uint32_t done = have ? p.iterations - (rem_w != 0xFFFFFFFFu ? rem_w : it) : 0u;
+                const uint32_t mx = sgpr(__ockl_wfred_max_u32(done));
+                if (p.stats && lane == 0) {
+                    unsigned long long *q = p.stats + 64 + 4 * (size_t)(slot >> 6);
+                    q[1] = wall_clock64();
+                    q[2] = (unsigned long long)tl_lds | ((unsigned long long)tl_dir << 32);
+                    q[3] = (unsigned long long)tl_rounds | ((unsigned long long)mx << 32);
+                }
+            }
+#endif
         }
     }
 #undef VRT_TL
