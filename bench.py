@@ -253,7 +253,17 @@ def main():
     opts = capi.default_options(kernel=kern, sort_rays=args.sort, slab_lds_bytes=args.lds_bytes, schedule=args.schedule)
     stream = torch.cuda.current_stream().cuda_stream
 
+    # N > 1 over RCCL: double-buffered records, the gather of step k overlaps the march of step k+1
+    # (volumeraytracer_amd.distributed.RecordGather); the gloo rehearsal stages through host memory instead
+    pipe = D.RecordGather(n, counts, dev, dst=0) if (world > 1 and not args.rehearse) else None
+
     def step():
+        if pipe is not None:
+            b_ep, b_ed, b_ei, b_rl = D.record_views(pipe.buffer(), n)
+            eng.trace_device(capi.VRT_F32, n, d_sp.data_ptr(), d_sd.data_ptr(), b_ep.data_ptr(), b_ed.data_ptr(),
+                             b_ei.data_ptr(), b_rl.data_ptr(), inv, args.iterations, stream=stream, options=opts)
+            pipe.launch()
+            return
         eng.trace_device(capi.VRT_F32, n, d_sp.data_ptr(), d_sd.data_ptr(), o_ep.data_ptr(), o_ed.data_ptr(),
                          o_ei.data_ptr(), o_rl.data_ptr(), inv, args.iterations, stream=stream, options=opts)
         if world > 1:
@@ -261,6 +271,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if pipe is not None:
+        pipe.finish()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -268,6 +280,8 @@ def main():
     t_begin = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if pipe is not None:
+        pipe.finish()                                              # every gather of the timed steps has completed
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -80,6 +80,51 @@ def test_two_rank_gather_matches_single_process():
     assert np.all(got["remaining_light"] == 0xFFFFFFFF)
 
 
+def _pipe_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 1000 + 37 * rank                                   # uneven shards
+        counts = [None] * world
+        dist.all_gather_object(counts, n)
+        pipe = D.RecordGather(n, counts, "cpu")
+        steps = 5
+        for k in range(steps):
+            buf = pipe.buffer()
+            assert buf.numel() == D.RECORD_WORDS * n
+            buf.copy_(torch.arange(buf.numel(), dtype=torch.int32) + 100000 * rank + 7 * k)   # "march" of step k
+            pipe.launch()
+        recs = pipe.finish()
+        if rank == 0:
+            q.put([r.clone().numpy() for r in recs])
+        else:
+            assert recs is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_double_buffered_gather_pipeline():
+    """RecordGather: the gather of step k overlaps step k+1 (two buffers); after finish() rank 0 holds every
+    rank's record of the LAST step, trimmed to that rank's ray count."""
+    world, steps = 2, 5
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for r in range(world):
+        n = 1000 + 37 * r
+        want = np.arange(D.RECORD_WORDS * n, dtype=np.int32) + 100000 * r + 7 * (steps - 1)
+        assert np.array_equal(got[r], want)
+
+
 def test_ray_range_partition():
     for n in (0, 1, 7, 64, 1000, 1048576):
         for world in (1, 2, 3, 8):

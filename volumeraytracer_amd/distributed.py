@@ -57,6 +57,53 @@ def gather_records(local, counts, dst=0, group=None):
     return [recv[r][:RECORD_WORDS * counts[r]] for r in range(world)]
 
 
+class RecordGather:
+    """Double-buffered gather of per-rank records to `dst`: the gather of step k runs on the collective's own
+    stream while step k+1 marches into the other buffer, so the only exchange on the path costs no step time.
+
+        pipe = RecordGather(n_local, counts, device)
+        for each step:
+            buf = pipe.buffer()          # waits until the gather that last used this buffer is done
+            ... march into record_views(buf, n_local) on the current stream ...
+            pipe.launch()                # async gather of buf (ordered after the current stream's work)
+        records = pipe.finish()          # all gathers complete; dst gets the last step's records, others None
+    """
+
+    def __init__(self, n_local, counts, device, dst=0, group=None, depth=2):
+        import torch.distributed as dist
+        self.dist, self.group, self.dst = dist, group, dst
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.n, self.counts, self.nmax = int(n_local), list(counts), max(counts)
+        self.bufs = [torch.zeros(RECORD_WORDS * self.nmax, dtype=torch.int32, device=device) for _ in range(depth)]
+        self.recv = [[torch.empty_like(self.bufs[0]) for _ in range(self.world)] if self.rank == dst else None
+                     for _ in range(depth)]
+        self.work = [None] * depth
+        self.k = 0
+        self.last = None
+
+    def buffer(self):
+        i = self.k % len(self.bufs)
+        if self.work[i] is not None:
+            self.work[i].wait()
+            self.work[i] = None
+        return self.bufs[i][:RECORD_WORDS * self.n]
+
+    def launch(self):
+        i = self.k % len(self.bufs)
+        self.work[i] = self.dist.gather(self.bufs[i], self.recv[i], dst=self.dst, group=self.group, async_op=True)
+        self.last = i
+        self.k += 1
+
+    def finish(self):
+        for i, w in enumerate(self.work):
+            if w is not None:
+                w.wait()
+                self.work[i] = None
+        if self.rank != self.dst or self.last is None:
+            return None
+        return [self.recv[self.last][r][:RECORD_WORDS * self.counts[r]] for r in range(self.world)]
+
+
 def assemble(records, counts):
     """dst side: concatenate per-rank records back into whole-job arrays in global ray order
     (rank r's rays precede rank r+1's).  Returns dict of numpy arrays (bit patterns, uint32)."""
