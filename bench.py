@@ -103,11 +103,11 @@ def synth_density_device(N, dev, seed=1234, nblobs=4):
     return dens
 
 
-def make_rays(cfg, rank, world):
+def make_rays(cfg, rank, world, band=None):
     gen = W.perspective_rays if cfg["gen"] == "perspective" else W.ortho_rays
     R = cfg["R"]
-    # weak scaling: a (R*world) x R lattice, rank r marches one contiguous band of R rows
-    return gen(cfg["N"], R, rows_total=R * world, row_range=D.row_band(R * world, rank, world))
+    # weak scaling: a (R*world) x R lattice, rank r marches one contiguous band of rows (R rows unless rebalanced)
+    return gen(cfg["N"], R, rows_total=R * world, row_range=band if band is not None else D.row_band(R * world, rank, world))
 
 
 def cpu_baseline(field_host, bounds, sp, sd, inv, iterations, gpu_out, budget_s, log):
@@ -186,6 +186,7 @@ def main():
     ap.add_argument("--iterations", type=int, default=100000)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget; 0 disables it")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
+    ap.add_argument("--no-rebalance", action="store_true", help="N > 1: keep equal-count row bands (no work rebalancing)")
     ap.add_argument("--rehearse", action="store_true",
                     help="development: let several ranks share one GPU (local_rank %% device_count) to exercise the "
                          "multi-rank code path on a single-GPU box; timings are meaningless")
@@ -240,6 +241,11 @@ def main():
         eng = capi.Engine.from_device(bounds, [x.data_ptr() for x in d], tr.data_ptr(), ftype, d[0].numel())
     log("field %s built on device in %.1f s (%.2f GB resident)" % (cfg["name"], time.time() - t0, eng.field_bytes / 1e9))
 
+    inv = [1.0, 1.0, 1.0]
+    kern = {"auto": capi.KERNEL_AUTO, "direct": capi.KERNEL_DIRECT, "slab": capi.KERNEL_SLAB}[args.kernel]
+    opts = capi.default_options(kernel=kern, sort_rays=args.sort, slab_lds_bytes=args.lds_bytes, schedule=args.schedule)
+    stream = torch.cuda.current_stream().cuda_stream
+
     sp, sd = make_rays(cfg, rank, world)
     n = sp.size // 3
     d_sp = torch.from_numpy(sp.view(np.int32)).to(dev)
@@ -247,11 +253,32 @@ def main():
     # one contiguous output record per rank: [end_pos 3n | end_dir 3n | end_iter n | light n] (32 B/ray)
     out = D.alloc_record(n, dev)
     o_ep, o_ed, o_ei, o_rl = D.record_views(out, n)
+    band = None
+    if world > 1 and not args.no_rebalance:
+        # equal ray counts leave the ranks skewed (rays at the rim of the image leave the volume
+        # early: 1.5e9 .. 3.7e9 ray-steps per rank at N = 8), so the bands are re-cut for equal measured work.
+        # Untimed set-up: one march of the equal bands, per-row step sums exchanged, contiguous bands of equal
+        # work (volumeraytracer_amd.distributed.balanced_bands), rays regenerated.
+        eng.trace_device(capi.VRT_F32, n, d_sp.data_ptr(), d_sd.data_ptr(), o_ep.data_ptr(), o_ed.data_ptr(),
+                         o_ei.data_ptr(), o_rl.data_ptr(), inv, args.iterations, stream=stream, options=opts)
+        torch.cuda.synchronize()
+        row_work = o_ei.to(torch.int64).reshape(-1, cfg["R"]).sum(1).to(torch.float64).to(cdev)
+        rows_all = [torch.empty_like(row_work) for _ in range(world)]
+        dist.all_gather(rows_all, row_work)
+        bands = D.balanced_bands(torch.cat(rows_all).cpu().numpy(), world)
+        band = bands[rank]
+        log("rebalanced row bands:", bands)
+        sp, sd = make_rays(cfg, rank, world, band)
+        n = sp.size // 3
+        d_sp = torch.from_numpy(sp.view(np.int32)).to(dev)
+        d_sd = torch.from_numpy(sd).to(dev)
+        out = D.alloc_record(n, dev)
+        o_ep, o_ed, o_ei, o_rl = D.record_views(out, n)
     counts = [n] * world
-    inv = [1.0, 1.0, 1.0]
-    kern = {"auto": capi.KERNEL_AUTO, "direct": capi.KERNEL_DIRECT, "slab": capi.KERNEL_SLAB}[args.kernel]
-    opts = capi.default_options(kernel=kern, sort_rays=args.sort, slab_lds_bytes=args.lds_bytes, schedule=args.schedule)
-    stream = torch.cuda.current_stream().cuda_stream
+    if world > 1:
+        cnt = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)]
+        dist.all_gather(cnt, torch.tensor([n], dtype=torch.int64, device=cdev))
+        counts = [int(c.item()) for c in cnt]
 
     # N > 1 over RCCL: double-buffered records, the gather of step k overlaps the march of step k+1
     # (volumeraytracer_amd.distributed.RecordGather); the gloo rehearsal stages through host memory instead
@@ -344,7 +371,9 @@ def main():
         "data": "synthetic",
         "config": {"workload": cfg["name"] + ", invscale 1, cap %d" % args.iterations,
                    "rays_per_gpu": n, "ray_steps_per_gpu": steps_local, "field_bytes": eng.field_bytes,
-                   "kernel": args.kernel, "sort": args.sort, "parallelism": "rays sharded in %d row bands, field replicated, RCCL gather to rank 0" % world if world > 1 else "single GPU"},
+                   "kernel": args.kernel, "sort": args.sort, "parallelism": ("rays sharded in %d row bands%s, field replicated, RCCL gather to rank 0"
+                                   % (world, "" if args.no_rebalance else " of equal measured work")) if world > 1 else "single GPU",
+                   "rays_total": int(sum(counts))},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel_ms": kavg_ms, "algorithmic_bytes_per_ray_step": bytes_per_step,

@@ -134,3 +134,22 @@ def test_ray_range_partition():
                 assert a[1] == b[0]
             sizes = [e - b for b, e in ranges]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_balanced_bands():
+    rng = np.random.RandomState(3)
+    for world in (2, 3, 4, 8):
+        for rows in (world, 17, 1024):
+            w = rng.rand(rows) ** 3 * 1000.0
+            bands = D.balanced_bands(w, world)
+            assert bands[0][0] == 0 and bands[-1][1] == rows
+            assert all(b[1] > b[0] for b in bands)
+            assert all(bands[i][1] == bands[i + 1][0] for i in range(world - 1))
+            if rows >= 64 * world:                      # fine-grained rows: every band within a few rows' work of the mean
+                work = np.array([w[a:b].sum() for a, b in bands])
+                assert work.max() - work.min() <= 4 * w.max()
+    assert D.balanced_bands(np.zeros(10), 2) == [(0, 5), (5, 10)]
+    # a skewed profile (short rays at the rim, long in the middle) gives wide outer bands and narrow inner ones
+    prof = np.concatenate([np.linspace(1, 10, 512), np.linspace(10, 1, 512)])
+    b = D.balanced_bands(prof, 4)
+    assert (b[0][1] - b[0][0]) > (b[1][1] - b[1][0]) and (b[3][1] - b[3][0]) > (b[2][1] - b[2][0])

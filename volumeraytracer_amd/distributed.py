@@ -27,6 +27,29 @@ def row_band(rows_total, rank, world):
     return ray_range(rows_total, rank, world)
 
 
+def balanced_bands(row_work, world):
+    """Contiguous row bands of (nearly) equal work: row_work[i] = measured ray-steps of lattice row i (any
+    non-negative weights).  Returns [(begin, end)] * world covering all rows, every band at least one row.
+    SURVEY 8(e): balance by ray count first, by measured steps if the counts leave the ranks skewed."""
+    w = np.maximum(np.asarray(row_work, dtype=np.float64), 0.0)
+    rows = w.size
+    assert rows >= world
+    csum = np.concatenate([[0.0], np.cumsum(w)])
+    total = csum[-1]
+    if total <= 0.0:
+        return [ray_range(rows, r, world) for r in range(world)]
+    cuts = [0]
+    for r in range(1, world):
+        c = int(np.searchsorted(csum, total * r / world, side="left"))     # first row index whose prefix reaches the share
+        if c > 0 and abs(csum[c - 1] - total * r / world) <= abs(csum[min(c, rows)] - total * r / world):
+            c -= 1
+        c = max(c, cuts[-1] + 1)                                            # at least one row per band ...
+        c = min(c, rows - (world - r))                                      # ... for the ranks still to come as well
+        cuts.append(c)
+    cuts.append(rows)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
 def record_views(buf, n):
     """Views into one rank's contiguous output record [end_pos 3n | end_dir 3n | end_iter n | light n]
     (int32 storage; end_dir holds float32 or int16-widened bits as written by the engine)."""
