@@ -332,3 +332,20 @@ def test_persistent_schedule(fdt, ddt):
             for sort in (-1, 1, 3):
                 got = eng.trace(sp, sd, inv, cap, options=_opts(capi.KERNEL_SLAB, sort, schedule=2))
                 _assert_same(got, want, ctx="inv=%s cap=%d sort=%d" % (inv, cap, sort))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 129, 257])
+def test_tiny_launches_with_forced_order_and_schedule(n):
+    """Ray counts around the wavefront size with every launch-order / schedule feature forced on: one group
+    (the persistent schedule then falls back to the static launch), a ragged second group, a few groups."""
+    N = 24
+    bounds, dx, dy, dz, tc = W.seam_field(N, np.float32, opaque_radius=3.0)
+    field = oracle.port.interleave(dx, dy, dz, tc)
+    sp, sd = W.random_rays(N, n, seed=n, vol_seed=1234)
+    want = oracle.port.trace(field, bounds, sp, sd, [1, 1, 1], 5000)
+    with capi.Engine.from_host(bounds, [dx, dy, dz], tc) as eng:
+        for sort in (-1, 1, 2, 3):
+            for schedule in (1, 2):
+                got = eng.trace(sp, sd, [1, 1, 1], 5000, options=_opts(capi.KERNEL_SLAB, sort, schedule=schedule))
+                _assert_same(got, want, ctx="n=%d sort=%d schedule=%d" % (n, sort, schedule))
