@@ -34,6 +34,16 @@ __global__ __launch_bounds__(256) void k(unsigned *out, unsigned ua, unsigned ub
         if (OP == 17) { FOUR("v_add_f32 %0, %0, %1\n") }
         if (OP == 18) { FOUR("v_cndmask_b32 %0, %0, %1, vcc\n") }
         if (OP == 19) { FOUR("v_bfe_i32 %0, %0, 1, 31\n") }
+        if (OP == 20) { FOUR("v_mul_lo_u32 %0, %0, %1\n") }
+        if (OP == 21) { FOUR("v_mul_hi_u32 %0, %0, %1\n") }
+        if (OP == 22) {
+            unsigned long long q0 = u0, q1 = u1, q2 = u2, q3 = u3;
+            REP16(asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n" : "+v"(q0) : "v"(ua), "v"(ub) : "vcc"); asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n" : "+v"(q1) : "v"(ua), "v"(ub) : "vcc");
+                  asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n" : "+v"(q2) : "v"(ua), "v"(ub) : "vcc"); asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n" : "+v"(q3) : "v"(ua), "v"(ub) : "vcc");)
+            u0 = (unsigned)q0; u1 = (unsigned)q1; u2 = (unsigned)q2; u3 = (unsigned)q3;
+        }
+        if (OP == 23) { FOUR("v_mul_u32_u24 %0, %0, %1\n") }
+        if (OP == 24) { REP16(asm volatile("v_add_co_u32 %0, vcc, %0, %1\n v_addc_co_u32 %0, vcc, %0, %2, vcc\n" : "+v"(u0) : "v"(ua), "v"(ub) : "vcc"); asm volatile("v_add_co_u32 %0, vcc, %0, %1\n v_addc_co_u32 %0, vcc, %0, %2, vcc\n" : "+v"(u1) : "v"(ua), "v"(ub) : "vcc");) }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = u0 + u1 + u2 + u3;
 }
@@ -63,5 +73,6 @@ int main()
     run<4>("v_lshl_add_u32"); run<8>("v_mad_u32_u24"); run<5>("v_cvt_i32_f32"); run<15>("v_cvt_flr_i32_f32");
     run<14>("v_cvt_f32_u32"); run<6>("v_cvt_f32_u32_sdwa"); run<7>("v_sub_u32_sdwa"); run<16>("v_rndne_f32");
     run<9>("v_max3_f32 |abs|"); run<10>("v_cmp_gt_u32 (x2)"); run<18>("v_cndmask_b32");
+    run<20>("v_mul_lo_u32"); run<21>("v_mul_hi_u32"); run<22>("v_mad_u64_u32"); run<23>("v_mul_u32_u24"); run<24>("v_add_co+v_addc_co");
     return 0;
 }

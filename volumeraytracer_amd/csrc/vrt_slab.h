@@ -55,8 +55,8 @@ constexpr int kSlabMinK = VRT_SLAB_MINK; // rounds shorter than this are not wor
 __device__ __forceinline__ uint32_t sgpr(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 // wave-uniform "some active lane has b": the compare mask itself (no 0/1 materialisation as with __ballot(int))
 __device__ __forceinline__ bool any_lane(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
-// a * b + c with a, b < 2^24 in one full-rate instruction (the compiler otherwise picks the quarter-rate
-// v_mad_u64_u32 for the brick address); b is wave-uniform
+// a * b + c with a, b < 2^24 in one instruction (the compiler otherwise builds the brick address from
+// v_mad_u64_u32 + v_mul_u32_u24 + two shifts + v_add3); b is wave-uniform
 __device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c)
 {
     uint32_t d;
