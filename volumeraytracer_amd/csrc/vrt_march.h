@@ -157,21 +157,27 @@ __device__ __forceinline__ bool march_step(Ray &r, const f4 (&c)[8], float invx,
     // t = (dir*inv)*(2*ilen) == 2s bit for bit; its truncation keeps the half bit and
     // roundf(s) == (trunc(2s) + 1 + sign) >> 1 (arithmetic): for trunc >= 0 that is (t+1)>>1, for
     // trunc < 0 it is floor(t/2), i.e. round half away from zero.
-    const bool tame = div_window(dot);                      // false for NaN, inf, negative, tiny and huge dot
-    float ilen2;
-    if (tame) ilen2 = ilen2_short(dot);                     // == 2 * (0x42000000p0f / dot), proven exhaustively
-    else { const float ilen = 0x42000000p0f / dot; ilen2 = ilen + ilen; }
-    const float tx = (r.dx * invx) * ilen2, ty = (r.dy * invy) * ilen2, tz = (r.dz * invz) * ilen2;
-    // tame dot => dir and inv are finite and ilen2 is finite and nonzero, so t is finite or +-inf, never
-    // NaN, and fmaxf (which would drop a NaN) is a safe range test; everything else rounds the slow way
-    if (tame && fmaxf(fmaxf(__builtin_fabsf(tx), __builtin_fabsf(ty)), __builtin_fabsf(tz)) < 2147483648.0f) {
-        r.px += round_half_i32(tx);                         // |s| < 2^30: always, unless the direction has collapsed
-        r.py += round_half_i32(ty);
-        r.pz += round_half_i32(tz);
-    } else {                                                // includes NaN / inf: x86 cvttss2si semantics
+    auto round_slow = [&r](float tx, float ty, float tz) {  // NaN / inf / out of range: x86 cvttss2si semantics
         r.px += (uint32_t)round_to_i32(tx * 0.5f);
         r.py += (uint32_t)round_to_i32(ty * 0.5f);
         r.pz += (uint32_t)round_to_i32(tz * 0.5f);
+    };
+    if (!div_window(dot)) {                                 // NaN, inf, negative, tiny or huge dot: everything the long way
+        const float ilen = 0x42000000p0f / dot;
+        const float ilen2 = ilen + ilen;
+        round_slow((r.dx * invx) * ilen2, (r.dy * invy) * ilen2, (r.dz * invz) * ilen2);
+        return false;
+    }
+    const float ilen2 = ilen2_short(dot);                   // == 2 * (0x42000000p0f / dot), proven exhaustively
+    const float tx = (r.dx * invx) * ilen2, ty = (r.dy * invy) * ilen2, tz = (r.dz * invz) * ilen2;
+    // tame dot => dir and inv are finite and ilen2 is finite and nonzero, so t is finite or +-inf, never
+    // NaN, and fmaxf (which would drop a NaN) is a safe range test
+    if (fmaxf(fmaxf(__builtin_fabsf(tx), __builtin_fabsf(ty)), __builtin_fabsf(tz)) < 2147483648.0f) {
+        r.px += round_half_i32(tx);                         // |s| < 2^30: always, unless the direction has collapsed
+        r.py += round_half_i32(ty);
+        r.pz += round_half_i32(tz);
+    } else {
+        round_slow(tx, ty, tz);
     }
     return false;
 }
