@@ -349,3 +349,36 @@ def test_tiny_launches_with_forced_order_and_schedule(n):
             for schedule in (1, 2):
                 got = eng.trace(sp, sd, [1, 1, 1], 5000, options=_opts(capi.KERNEL_SLAB, sort, schedule=schedule))
                 _assert_same(got, want, ctx="n=%d sort=%d schedule=%d" % (n, sort, schedule))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_step_window_boundary(kernel):
+    """The step's fast path (short division + integer rounding) is taken iff |dir|^2 lies in a window whose lower
+    edge is (2C max|inv| / 2^31)^2 rounded up (vrt_march.h, StepWindow): inside it every doubled step component
+    is below 2^31 by construction (v_cvt_i32_f32 would saturate beyond), outside the general rounding runs.  Rays
+    whose |dir| straddles that edge within a few ulps, aligned with the axis of the largest invscale (worst
+    case) and in random directions, for several invscales -- any mis-set edge shows as a position mismatch."""
+    rng = np.random.RandomState(77)
+    B = [14, 15, 16]
+    n = B[0] * B[1] * B[2]
+    d = [(rng.randn(n) * 1e-4).astype(np.float32) for _ in range(3)]       # tiny gradients: |dir| stays where it starts
+    tc = np.full(n, 0xFFFFFFFF, np.uint32)
+    field = oracle.port.interleave(d[0], d[1], d[2], tc)
+    m = 6000
+    pv = 1.0 + rng.rand(m, 3) * (np.array(B) - 3.0)
+    sp = np.round(pv * 65536).astype(np.uint32).reshape(-1)
+    with capi.Engine.from_host(B, d, tc) as eng:
+        for inv in ([1, 1, 1], [3.0, 0.5, 1.0], [0.25, 0.25, 1000.0], [1e-3, 2e-3, 1e-3]):
+            edge = 2.0 * 1107296256.0 * max(inv) / 2147483648.0 / 65536.0   # |dir| (caller scale) at the window edge
+            axis = int(np.argmax(inv))
+            u = rng.randn(m, 3)
+            u /= np.linalg.norm(u, axis=1)[:, None]
+            u[: m // 2] = 0.0
+            u[: m // 2, axis] = np.where(rng.rand(m // 2) < 0.5, 1.0, -1.0)      # worst case: along the max-inv axis
+            mag = edge * (1.0 + rng.uniform(-3e-5, 3e-5, m))                      # within +-3e-5 of the edge (margin is 2^-17)
+            mag[::7] = edge * (1.0 + rng.uniform(-1e-7, 1e-7, mag[::7].size))     # and within an ulp or two
+            sd = (u * mag[:, None]).astype(np.float32).reshape(-1)
+            want = oracle.port.trace(field, B, sp, sd, inv, 6)
+            got = eng.trace(sp, sd, inv, 6, options=_opts(kernel))
+            _assert_same(got, want, ctx="inv=%s" % (inv,))

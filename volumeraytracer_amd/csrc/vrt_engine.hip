@@ -239,6 +239,31 @@ int launch_typed(vrt_engine *e, const vrt::MarchParams &p, int kernel, hipStream
     return VRT_OK;
 }
 
+// Fast-path window of |dir|^2 for this launch's invscale (vrt_march.h, StepWindow).
+void step_window(const float *inv, uint32_t *lo, uint32_t *span)
+{
+    const uint32_t base_lo = 32u << 23, base_hi = 251u << 23;          // exhaustively verified short-division range
+    *lo = base_lo;
+    *span = 0;                                                          // empty unless everything below is finite
+    const double m = std::max(std::fabs((double)inv[0]), std::max(std::fabs((double)inv[1]), std::fabs((double)inv[2])));
+    if (!(m < 1.0e30)) return;                                          // NaN or absurd invscale: always the long way
+    const double b = 2.0 * 1107296256.0 * m / 2147483648.0;             // 2C * max|inv| / 2^31
+    const double t = b * b * (1.0 + 1.0 / 65536.0);
+    uint32_t need = base_lo;
+    if (t > 0.0) {
+        float tf = (float)t;
+        if ((double)tf < t) tf = std::nextafterf(tf, INFINITY);
+        if (!(tf < 3.0e38f)) return;
+        uint32_t bits;
+        memcpy(&bits, &tf, 4);
+        need = bits + 1u;                                               // strictly above the bound
+    }
+    const uint32_t l = std::max(base_lo, need);
+    if (l >= base_hi) return;
+    *lo = l;
+    *span = base_hi - l;
+}
+
 int trace_device_impl(vrt_engine *e, int dir_type, size_t nrays, const uint32_t *d_sp, const void *d_sd,
                       uint32_t *d_ep, void *d_ed, uint32_t *d_ei, uint32_t *d_rl, uint32_t *d_path,
                       const float *invscale, uint32_t iterations, hipStream_t s, const vrt_options *opt,
@@ -250,6 +275,7 @@ int trace_device_impl(vrt_engine *e, int dir_type, size_t nrays, const uint32_t 
     p.field = e->field;
     p.Bx = e->B[0]; p.By = e->B[1]; p.Bz = e->B[2];
     p.invx = invscale[0]; p.invy = invscale[1]; p.invz = invscale[2];
+    step_window(invscale, &p.win_lo, &p.win_span);
     p.start_pos = d_sp; p.start_dir = d_sd;
     p.end_pos = d_ep; p.end_dir = d_ed; p.end_iter = d_ei; p.remaining_light = d_rl;
     p.path = d_path;

@@ -22,6 +22,7 @@ struct MarchParams {
     const void *field;        // AoS {dx,dy,dz,w} per voxel, index ((x*By)+y)*Bz+z
     uint32_t Bx, By, Bz;      // field extents
     float invx, invy, invz;   // invscale
+    uint32_t win_lo, win_span; // fast-path window of |dir|^2 as float bit patterns, see StepWindow / step_window()
     const uint32_t *start_pos;
     const void *start_dir;
     uint32_t *end_pos;
@@ -102,6 +103,15 @@ __device__ __forceinline__ void cvt_vox(const vox_i16 &v, f4 &o)
 // ---- one march step given the 8 corners ------------------------------------------------
 // c[k]: k = 4*hi_x + 2*hi_y + hi_z.  Returns true if the ray terminates on the w>0 test.
 
+// Fast-path window of dot = |dir|^2, as float bit patterns: the step takes the short division and the integer
+// rounding iff (bits(dot) - lo) < span (unsigned; NaN, inf, negative values wrap out).  Two conditions are folded into it:
+//   (1) the exhaustively verified range of the short division, biased exponents 32..250 (div_window);
+//   (2) |t| < 2^31 for the three step components t_d = (dir_d * inv_d) * (2C / dot), which the integer rounding
+//       needs: |dir_d| <= sqrt(dot), so |t_d| <= 2C * max|inv| / sqrt(dot) < 2^31  <=>  dot > (2C * max|inv| / 2^31)^2.
+//       The host (step_window) rounds that bound up by 2^-16, far more than the few 2^-24 the float evaluation of
+//       dot, 2C/dot and the two products can add, so no per-step range test remains.
+struct StepWindow { uint32_t lo, span; };
+
 struct Ray {
     uint32_t px, py, pz;
     float dx, dy, dz;        // internal scale, unit 1.0 == 65536 (.cu:328-331)
@@ -110,7 +120,7 @@ struct Ray {
 // check_w == false promises that none of the eight corners has w > 0 (the slab kernel knows this for a
 // whole brick from a ballot taken while staging it), so the opacity test cannot fire and is skipped.
 __device__ __forceinline__ bool march_step(Ray &r, const f4 (&c)[8], float invx, float invy, float invz,
-                                           bool check_w = true)
+                                           StepWindow win, bool check_w = true)
 {
     // wl = 0x10000 - wr is formed in float: both are integers below 2^17, so the subtraction is exact
     // and equals the reference's (float)(0x10000 - multr) (.cu:145-153)
@@ -162,23 +172,16 @@ __device__ __forceinline__ bool march_step(Ray &r, const f4 (&c)[8], float invx,
         r.py += (uint32_t)round_to_i32(ty * 0.5f);
         r.pz += (uint32_t)round_to_i32(tz * 0.5f);
     };
-    if (!div_window(dot)) {                                 // NaN, inf, negative, tiny or huge dot: everything the long way
+    if (!((__float_as_uint(dot) - win.lo) < win.span)) {    // outside the window: everything the long way
         const float ilen = 0x42000000p0f / dot;
         const float ilen2 = ilen + ilen;
         round_slow((r.dx * invx) * ilen2, (r.dy * invy) * ilen2, (r.dz * invz) * ilen2);
         return false;
     }
     const float ilen2 = ilen2_short(dot);                   // == 2 * (0x42000000p0f / dot), proven exhaustively
-    const float tx = (r.dx * invx) * ilen2, ty = (r.dy * invy) * ilen2, tz = (r.dz * invz) * ilen2;
-    // tame dot => dir and inv are finite and ilen2 is finite and nonzero, so t is finite or +-inf, never
-    // NaN, and fmaxf (which would drop a NaN) is a safe range test
-    if (fmaxf(fmaxf(__builtin_fabsf(tx), __builtin_fabsf(ty)), __builtin_fabsf(tz)) < 2147483648.0f) {
-        r.px += round_half_i32(tx);                         // |s| < 2^30: always, unless the direction has collapsed
-        r.py += round_half_i32(ty);
-        r.pz += round_half_i32(tz);
-    } else {
-        round_slow(tx, ty, tz);
-    }
+    r.px += round_half_i32((r.dx * invx) * ilen2);          // |t| < 2^31 inside the window (StepWindow, condition 2)
+    r.py += round_half_i32((r.dy * invy) * ilen2);
+    r.pz += round_half_i32((r.dz * invz) * ilen2);
     return false;
 }
 
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(256) void k_march_direct(const MarchParams p)
         if constexpr (ABSORB) { if (absorb_step(p, r, light)) break; }   // .cu:337-341
         f4 c[8];
         gather_global<FieldT>(f, r, p.By, p.Bz, c);
-        if (march_step(r, c, p.invx, p.invy, p.invz)) break;
+        if (march_step(r, c, p.invx, p.invy, p.invz, StepWindow{p.win_lo, p.win_span})) break;
         if (PATH) path_put(pb, it, r, p.out_pos_bias);
     }
     ++it;                                               // .cu:350

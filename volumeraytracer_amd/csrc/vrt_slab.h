@@ -179,6 +179,7 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
     const uint32_t B[3] = {p.Bx, p.By, p.Bz};
     const uint32_t bx1 = (p.Bx - 1) & 0xFFFFu, by1 = (p.By - 1) & 0xFFFFu, bz1 = (p.Bz - 1) & 0xFFFFu;
     const float invx = p.invx, invy = p.invy, invz = p.invz;
+    const StepWindow win = {p.win_lo, p.win_span};
 
     // Per-ray state.  `it` is the reference's remaining-iterations counter (.cu:333-351): it drops by one per
     // completed step and the ray stops at it == 0, on leaving the field, or on w > 0; the value at
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                         } else {
                             gather_global<FieldT>(f, r, p.By, p.Bz, c);
                         }
-                        if (march_step(r, c, invx, invy, invz)) { rem_w = it; it = 0; } else --it;
+                        if (march_step(r, c, invx, invy, invz, win)) { rem_w = it; it = 0; } else --it;
                     }
                 }
             }
@@ -368,9 +369,9 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                             f4 c[8];
                             gather_lds(seg, mad24(mad24(cx, ey, cy), ez, cz), sy, sx, c);
                             if constexpr (kHasW) {
-                                if (march_step(r, c, invx, invy, invz, true)) { rem_w = it; it = 0; } else --it;
+                                if (march_step(r, c, invx, invy, invz, win, true)) { rem_w = it; it = 0; } else --it;
                             } else {
-                                (void)march_step(r, c, invx, invy, invz, false);
+                                (void)march_step(r, c, invx, invy, invz, win, false);
                                 --it;
                             }
                         }
