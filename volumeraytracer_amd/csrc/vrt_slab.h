@@ -342,10 +342,14 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
             // two copies of the loop: in a brick without any positive w (the common case) the opacity test
             // cannot fire, so that copy carries neither the test nor the rem_w bookkeeping
             const int Ku = (int)sgpr((uint32_t)K);                       // keep the trip count in an SGPR
+            // inside the round the positions are kept relative to the brick origin (its low 16 bits are zero, so
+            // the weights and every position update are unchanged): the cell is then one shift, not an SDWA subtract
+            const uint32_t ox = lox << 16, oy = loy << 16, oz = loz << 16;
+            r.px -= ox; r.py -= oy; r.pz -= oz;
             auto run = [&](auto has_w) {
                 constexpr bool kHasW = decltype(has_w)::value;
                 for (int k = 0; k < Ku; ++k) {
-                    const uint32_t cx = (r.px >> 16) - lox, cy = (r.py >> 16) - loy, cz = (r.pz >> 16) - loz;
+                    const uint32_t cx = r.px >> 16, cy = r.py >> 16, cz = r.pz >> 16;
                     const bool inb = cx < ex1 && cy < ey1 && cz < ez1;   // cell and its +1 neighbours are staged
                     const bool pos = it > 0;
                     // wave-level tests on the compare masks themselves (scalar ALU): a ballot of a compound
@@ -355,7 +359,8 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                     if ((m_pos & ~m_inb) != 0ull) {                      // rare: some lane is outside the brick
                         // the brick is clipped to the field, so a ray that left the field is outside the brick too
                         // and simply stops marching; a ray still inside the field forces a new plan
-                        if (any_lane(pos && !inb && in_field(r, bx1, by1, bz1))) { stat_add(p, kStatEarlyExit, 1); break; }
+                        const bool inf = ((r.px + ox) >> 16) < bx1 && ((r.py + oy) >> 16) < by1 && ((r.pz + oz) >> 16) < bz1;
+                        if (any_lane(pos && !inb && inf)) { stat_add(p, kStatEarlyExit, 1); break; }
                     }
                     const bool alive = pos && inb;                       // inside the brick => inside the field
                     if ((m_pos & m_inb) == 0ull) break;
@@ -363,7 +368,11 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                     VRT_TL(++tl_lds);
                         if (alive) {
                         bool dark = false;
-                        if constexpr (ABSORB) dark = absorb_step(p, r, light);
+                        if constexpr (ABSORB) {
+                            Ray ra = r;
+                            ra.px += ox; ra.py += oy; ra.pz += oz;
+                            dark = absorb_step(p, ra, light);
+                        }
                         if (dark) { rem_w = it; it = 0; }
                         else {
                             f4 c[8];
@@ -379,6 +388,7 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                 }
             };
             if (brick_has_w) run(std::true_type{}); else run(std::false_type{});
+            r.px += ox; r.py += oy; r.pz += oz;
         }
     }
     };  // march
