@@ -348,13 +348,24 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
             r.px -= ox; r.py -= oy; r.pz -= oz;
             auto run = [&](auto has_w) {
                 constexpr bool kHasW = decltype(has_w)::value;
-                for (int k = 0; k < Ku; ++k) {
+                constexpr bool kDies = kHasW || ABSORB;              // a ray can stop inside the round for another reason
+                // Without the opacity test a ray can stop inside a round only by leaving the brick or by using up its
+                // iterations; the round is capped at the smallest remaining count, so "has iterations left" is a
+                // per-round constant there and costs no compare per step (absorption mode can darken a ray mid-round: kDies).
+                const bool pos0 = it > 0;
+                int Kr = Ku;
+                if constexpr (!kDies) {
+                    const uint32_t min_it = sgpr(__ockl_wfred_min_u32(pos0 ? it : 0xFFFFFFFFu));
+                    Kr = (uint32_t)Ku < min_it ? Ku : (int)min_it;
+                }
+                const uint64_t m_pos0 = lane_mask(pos0);
+                for (int k = 0; k < Kr; ++k) {
                     const uint32_t cx = r.px >> 16, cy = r.py >> 16, cz = r.pz >> 16;
                     const bool inb = cx < ex1 && cy < ey1 && cz < ez1;   // cell and its +1 neighbours are staged
-                    const bool pos = it > 0;
+                    const bool pos = kDies ? it > 0 : pos0;
                     // wave-level tests on the compare masks themselves (scalar ALU): a ballot of a compound
                     // bool would be materialised through v_cndmask + v_cmp
-                    const uint64_t m_pos = lane_mask(it > 0);
+                    const uint64_t m_pos = kDies ? lane_mask(it > 0) : m_pos0;
                     const uint64_t m_inb = lane_mask(cx < ex1) & lane_mask(cy < ey1) & lane_mask(cz < ez1);
                     if ((m_pos & ~m_inb) != 0ull) {                      // rare: some lane is outside the brick
                         // the brick is clipped to the field, so a ray that left the field is outside the brick too
