@@ -39,6 +39,9 @@ constexpr int kSlabWavesPerBlock = 4;
 #ifndef VRT_PRIO_DIRECT
 #define VRT_PRIO_DIRECT 3
 #endif
+#ifndef VRT_SWEEP_REFRESH
+#define VRT_SWEEP_REFRESH 8
+#endif
 #ifndef VRT_SLAB_MAXK
 #define VRT_SLAB_MAXK 192
 #endif
@@ -198,36 +201,49 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
 
     // march(): advances the wavefront's rays until all of them have stopped
     auto march = [&]() {
+    uint32_t plan_round = 0;                            // wave-uniform
+    int32_t sweep_neg[3] = {0, 0, 0}, sweep_pos[3] = {0, 0, 0};
     for (;;) {
         const bool live = it > 0 && in_field(r, bx1, by1, bz1);
         if (!any_lane(live)) return;             // wave early-out: every lane has terminated
 
         // ---- plan -------------------------------------------------------------------------
-        int32_t s[3];
-        {                                               // per-step displacement estimate from the current direction
-            const float dot = fma_(r.dz, r.dz, fma_(r.dx, r.dx, r.dy * r.dy));
-            const float ilen = 0x42000000p0f * __builtin_amdgcn_rcpf(dot);   // estimate only
-            const float lim = 268435456.0f;             // 2^28
-            s[0] = (int32_t)fminf(fmaxf((r.dx * invx) * ilen, -lim), lim);
-            s[1] = (int32_t)fminf(fmaxf((r.dy * invy) * ilen, -lim), lim);
-            s[2] = (int32_t)fminf(fmaxf((r.dz * invz) * ilen, -lim), lim);
-        }
+        // A wave reduction costs about 50 cycles (five DPP stages with their hazard slots, two readlanes), twelve
+        // of them more than a whole march step.  The six position bounds are needed for every brick; the six
+        // displacement bounds change slowly (the direction moves by g * inv per step), so they are refreshed every
+        // VRT_SWEEP_REFRESH-th round only -- a stale bound can only make the brick-exit test end a round early.
         PlanIn in;
+        if ((plan_round++ % VRT_SWEEP_REFRESH) == 0) {
+            int32_t s[3];
+            {                                           // per-step displacement estimate from the current direction
+                const float dot = fma_(r.dz, r.dz, fma_(r.dx, r.dx, r.dy * r.dy));
+                const float ilen = 0x42000000p0f * __builtin_amdgcn_rcpf(dot);   // estimate only
+                const float lim = 268435456.0f;         // 2^28
+                s[0] = (int32_t)fminf(fmaxf((r.dx * invx) * ilen, -lim), lim);
+                s[1] = (int32_t)fminf(fmaxf((r.dy * invy) * ilen, -lim), lim);
+                s[2] = (int32_t)fminf(fmaxf((r.dz * invz) * ilen, -lim), lim);
+            }
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int32_t smn = (int32_t)sgpr((uint32_t)__ockl_wfred_min_i32(live ? s[d] : 0x7FFFFFFF));
+                const int32_t smx = (int32_t)sgpr((uint32_t)__ockl_wfred_max_i32(live ? s[d] : (int32_t)0x80000000));
+                int32_t a = smn >> 8, c = (smx >> 8) + 1;          // floor / ceil (+1 keeps it conservative)
+                a = a > 0 ? 0 : (a < -(1 << 20) ? -(1 << 20) : a);
+                c = c < 0 ? 0 : (c > (1 << 20) ? (1 << 20) : c);
+                sweep_neg[d] = a;
+                sweep_pos[d] = c;
+            }
+        }
         {
             const uint32_t px[3] = {r.px, r.py, r.pz};
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 const uint32_t lo = sgpr(__ockl_wfred_min_u32(live ? px[d] : 0xFFFFFFFFu));
                 const uint32_t hi = sgpr(__ockl_wfred_max_u32(live ? px[d] : 0u));
-                const int32_t smn = (int32_t)sgpr((uint32_t)__ockl_wfred_min_i32(live ? s[d] : 0x7FFFFFFF));
-                const int32_t smx = (int32_t)sgpr((uint32_t)__ockl_wfred_max_i32(live ? s[d] : (int32_t)0x80000000));
                 in.pmin8[d] = (int32_t)(lo >> 8);
                 in.pmax8[d] = (int32_t)((hi >> 8) + 1);
-                int32_t a = smn >> 8, c = (smx >> 8) + 1;          // floor / ceil (+1 keeps it conservative)
-                a = a > 0 ? 0 : (a < -(1 << 20) ? -(1 << 20) : a);
-                c = c < 0 ? 0 : (c > (1 << 20) ? (1 << 20) : c);
-                in.sneg8[d] = a;
-                in.spos8[d] = c;
+                in.sneg8[d] = sweep_neg[d];
+                in.spos8[d] = sweep_pos[d];
             }
         }
         Brick bk;
