@@ -93,7 +93,7 @@ struct vrt_engine {
     // workspaces (grow-only; no allocation in steady state)
     DevBuf sort_keys, sort_keys_alt, sort_vals, sort_vals_alt, sort_tmp, sort_bounds;
     DevBuf transl;                 // translucency per field voxel, kept only for the opt-in absorption mode
-    DevBuf q_ctl;                  // group counter of the persistent slab kernel (vrt_options.schedule)
+    DevBuf group_ctr;                  // group counter of the persistent slab kernel (vrt_options.schedule)
     DevBuf stats;                  // debug counters, allocated only when VRT_DEBUG_STATS=1
     size_t stats_count = 0;
     DevBuf h_in_pos, h_in_dir, h_out_pos, h_out_dir, h_out_iter, h_out_light, h_path;
@@ -210,7 +210,7 @@ void engine_free(vrt_engine *e)
     if (e->field) (void)hipFree(e->field);
     if (e->ev_begin) (void)hipEventDestroy(e->ev_begin);
     if (e->ev_end) (void)hipEventDestroy(e->ev_end);
-    DevBuf *bufs[] = {&e->transl, &e->stats, &e->q_ctl, &e->sort_keys, &e->sort_keys_alt, &e->sort_vals, &e->sort_vals_alt, &e->sort_tmp, &e->sort_bounds,
+    DevBuf *bufs[] = {&e->transl, &e->stats, &e->group_ctr, &e->sort_keys, &e->sort_keys_alt, &e->sort_vals, &e->sort_vals_alt, &e->sort_tmp, &e->sort_bounds,
                       &e->h_in_pos, &e->h_in_dir, &e->h_out_pos, &e->h_out_dir, &e->h_out_iter, &e->h_out_light,
                       &e->h_path};
     for (DevBuf *b : bufs) b->release();
@@ -340,9 +340,9 @@ int trace_device_impl(vrt_engine *e, int dir_type, size_t nrays, const uint32_t 
         // auto: persistent once the launch has more wavefronts than the GPU holds (measured -4 % on config 3)
         if (schedule == 0) schedule = groups > (size_t)e->num_cu * 24 ? 2 : 1;
         if (schedule == 2 && kernel == VRT_KERNEL_SLAB && groups > 1) {
-            HIP_TRY(e->q_ctl.reserve(sizeof(uint32_t)));
-            HIP_TRY(hipMemsetAsync(e->q_ctl.p, 0, sizeof(uint32_t), s));
-            p.group_counter = (uint32_t *)e->q_ctl.p;
+            HIP_TRY(e->group_ctr.reserve(sizeof(uint32_t)));
+            HIP_TRY(hipMemsetAsync(e->group_ctr.p, 0, sizeof(uint32_t), s));
+            p.group_counter = (uint32_t *)e->group_ctr.p;
         }
     }
 
