@@ -103,11 +103,18 @@ def synth_density_device(N, dev, seed=1234, nblobs=4):
     return dens
 
 
-def make_rays(cfg, rank, world, band=None):
+def lattice_rows(cfg, world, scaling="weak"):
+    """Rows of the whole job's ray lattice (R columns each).  weak: every rank marches R rows, so the lattice grows to
+    (R*world) x R; strong: the lattice BASELINE names, R x R, is cut into `world` row bands (BASELINE config 4:
+    2048 x 2048 rays tiled across the GPUs of the node)."""
+    return cfg["R"] * world if scaling == "weak" else cfg["R"]
+
+
+def make_rays(cfg, rank, world, band=None, scaling="weak"):
     gen = W.perspective_rays if cfg["gen"] == "perspective" else W.ortho_rays
-    R = cfg["R"]
-    # weak scaling: a (R*world) x R lattice, rank r marches one contiguous band of rows (R rows unless rebalanced)
-    return gen(cfg["N"], R, rows_total=R * world, row_range=band if band is not None else D.row_band(R * world, rank, world))
+    rows = lattice_rows(cfg, world, scaling)
+    # rank r marches one contiguous band of rows (equal counts unless rebalanced)
+    return gen(cfg["N"], cfg["R"], rows_total=rows, row_range=band if band is not None else D.row_band(rows, rank, world))
 
 
 def cpu_baseline(field_host, bounds, sp, sd, inv, iterations, gpu_out, budget_s, log):
@@ -187,6 +194,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget; 0 disables it")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
     ap.add_argument("--no-rebalance", action="store_true", help="N > 1: keep equal-count row bands (no work rebalancing)")
+    ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
+                    help="N > 1: weak = every rank marches R rows of an (R*N) x R lattice (default); strong = the fixed R x R "
+                         "lattice cut into N row bands (default for config 4, which BASELINE defines that way)")
     ap.add_argument("--rehearse", action="store_true",
                     help="development: let several ranks share one GPU (local_rank %% device_count) to exercise the "
                          "multi-rank code path on a single-GPU box; timings are meaningless")
@@ -220,6 +230,7 @@ def main():
 
     cfg = CONFIGS[args.config]
     N = cfg["N"]
+    scaling = args.scaling if args.scaling != "auto" else ("strong" if args.config == 4 else "weak")
     t0 = time.time()
     scene = None
     if cfg.get("lut"):
@@ -246,7 +257,7 @@ def main():
     opts = capi.default_options(kernel=kern, sort_rays=args.sort, slab_lds_bytes=args.lds_bytes, schedule=args.schedule)
     stream = torch.cuda.current_stream().cuda_stream
 
-    sp, sd = make_rays(cfg, rank, world)
+    sp, sd = make_rays(cfg, rank, world, scaling=scaling)
     n = sp.size // 3
     d_sp = torch.from_numpy(sp.view(np.int32)).to(dev)
     d_sd = torch.from_numpy(sd).to(dev)
@@ -268,7 +279,7 @@ def main():
         bands = D.balanced_bands(torch.cat(rows_all).cpu().numpy(), world)
         band = bands[rank]
         log("rebalanced row bands:", bands)
-        sp, sd = make_rays(cfg, rank, world, band)
+        sp, sd = make_rays(cfg, rank, world, band, scaling=scaling)
         n = sp.size // 3
         d_sp = torch.from_numpy(sp.view(np.int32)).to(dev)
         d_sd = torch.from_numpy(sd).to(dev)
@@ -365,14 +376,15 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": cfg["name"] + ", invscale 1, cap %d" % args.iterations,
                    "rays_per_gpu": n, "ray_steps_per_gpu": steps_local, "field_bytes": eng.field_bytes,
-                   "kernel": args.kernel, "sort": args.sort, "parallelism": ("rays sharded in %d row bands%s, field replicated, RCCL gather to rank 0"
-                                   % (world, "" if args.no_rebalance else " of equal measured work")) if world > 1 else "single GPU",
+                   "kernel": args.kernel, "sort": args.sort, "parallelism": ("%s x %d ray lattice cut into %d row bands%s, field replicated, %s gather of 32 B/ray to rank 0"
+                                   % (lattice_rows(cfg, world, scaling), cfg["R"], world, "" if args.no_rebalance else " of equal measured work",
+                                      "gloo (rehearsal on one GPU, host staging)" if args.rehearse else "RCCL")) if world > 1 else "single GPU",
                    "rays_total": int(sum(counts))},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -1,0 +1,106 @@
+// step_rate.hip -- speed of light of the march step on gfx950: the production step (vrt_march.h, corners read from an
+// LDS brick exactly as the slab kernel's inner loop does) run back to back with no planning, no staging and no divergence,
+// at 1..8 wavefronts per SIMD.  Reports shader cycles per wave-step per SIMD at the clock the chip really holds
+// (s_memtime / s_memrealtime), i.e. the floor the slab kernel's marching phase can reach with this instruction mix.
+//   MODE 0  step + in-brick test (the slab kernel's loop body)
+//   MODE 1  step without the in-brick test
+//   MODE 2  step on corners held in registers (no LDS reads): the pure VALU cost
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -o step_rate step_rate.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include "../../volumeraytracer_amd/csrc/vrt_slab.h"
+
+using namespace vrt;
+
+template <int MODE, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_step(const vox_f32 *src, uint32_t *out, int nsteps, unsigned long long *clk,
+                                                   float invx, float invy, float invz, uint32_t win_lo, uint32_t win_span)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    vox_f32 *seg = (vox_f32 *)smem + (size_t)wave * 384;
+    for (int j = 0; j < 6; ++j) seg[lane + 64 * j] = src[lane + 64 * j];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // brick 8 x 6 x 8; rays start in cell (1..2, 1..2, 1..2) and are folded back every step
+    const uint32_t ey = 6, ez = 8, ex1 = 7, ey1 = 5, ez1 = 7;
+    Ray r;
+    r.px = 0x10000u + lane * 600u; r.py = 0x18000u + lane * 300u; r.pz = 0x14000u + lane * 450u;
+    r.dx = 65536.0f; r.dy = 100.0f * (float)lane; r.dz = -50.0f * (float)lane;
+    const StepWindow win = {win_lo, win_span};
+    uint32_t it = 0x7FFFFFFFu;
+    unsigned long long t0, t1, r0, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0) :: "memory");
+    f4 creg[8];
+    if (MODE == 2) gather_lds(seg, 60, ez, ey * ez, creg);
+    const uint32_t sy = ez, sx = ey * ez;
+    const uint64_t m_pos0 = lane_mask(it > 0);
+    for (int k = 0; k < nsteps; ++k) {
+        const uint32_t cx = r.px >> 16, cy = r.py >> 16, cz = r.pz >> 16;
+        if (MODE == 0) {
+            const uint64_t m_inb = lane_mask(cx < ex1) & lane_mask(cy < ey1) & lane_mask(cz < ez1);
+            if ((m_pos0 & ~m_inb) != 0ull) {
+                if (any_lane(!(cx < ex1 && cy < ey1 && cz < ez1) && r.px < 0x80000000u)) break;
+            }
+            if ((m_pos0 & m_inb) == 0ull) break;
+            if (cx < ex1 && cy < ey1 && cz < ez1) {
+                f4 c[8];
+                gather_lds(seg, mad24(mad24(cx, ey, cy), ez, cz), sy, sx, c);
+                (void)march_step(r, c, invx, invy, invz, win, false);
+                --it;
+            }
+        } else if (MODE == 1) {
+            f4 c[8];
+            gather_lds(seg, mad24(mad24(cx, ey, cy), ez, cz), sy, sx, c);
+            (void)march_step(r, c, invx, invy, invz, win, false);
+            --it;
+        } else {
+            (void)march_step(r, creg, invx, invy, invz, win, false);
+            --it;
+        }
+        // fold the ray back into cells 1..2 (3 VALU the production loop does not have)
+        r.px = (r.px & 0x1FFFFu) | 0x10000u; r.py = (r.py & 0x1FFFFu) | 0x10000u; r.pz = (r.pz & 0x1FFFFu) | 0x10000u;
+    }
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) :: "memory");
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r.px + r.py + r.pz + it + __float_as_uint(r.dx + r.dy + r.dz);
+    if (lane == 0) { atomicAdd(clk, t1 - t0); atomicAdd(clk + 1, r1 - r0); }
+}
+
+template <int MODE, int OCC> void run(const char *name, const vox_f32 *src)
+{
+    const int nsteps = 20000;
+    const int blocks = 256 * OCC;
+    uint32_t *out;
+    unsigned long long *clk, h[2];
+    hipMalloc(&out, (size_t)blocks * 256 * 4);
+    hipMalloc(&clk, 16);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const size_t lds = 4 * 384 * 16;
+    k_step<MODE, OCC><<<blocks, 256, lds>>>(src, out, nsteps, clk, 1.0f, 1.0f, 1.0f, 32u << 23, (251u - 32u) << 23);
+    hipDeviceSynchronize();
+    hipMemset(clk, 0, 16);
+    hipEventRecord(e0);
+    k_step<MODE, OCC><<<blocks, 256, lds>>>(src, out, nsteps, clk, 1.0f, 1.0f, 1.0f, 32u << 23, (251u - 32u) << 23);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+    const double clock = (double)h[0] / (double)h[1] * 100e6;
+    const double wave_steps_per_simd = (double)OCC * nsteps;
+    printf("%-28s waves/SIMD=%d  %.3f ms  clock %.3f GHz  %.1f cycles per wave-step per SIMD (%.1f at 2.4 GHz nominal)\n", name, OCC, ms,
+           clock / 1e9, ms * 1e-3 * clock / wave_steps_per_simd, ms * 1e-3 * 2.4e9 / wave_steps_per_simd);
+    hipFree(out); hipFree(clk);
+}
+
+int main()
+{
+    std::vector<float> h(384 * 4);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = (i % 4 == 3) ? -32767.0f : (float)((int)(i * 2654435761u % 2001u) - 1000) * 1.0e-3f;
+    vox_f32 *src;
+    hipMalloc(&src, h.size() * 4);
+    hipMemcpy(src, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    run<0, 1>("step+test (LDS)", src); run<0, 2>("step+test (LDS)", src); run<0, 3>("step+test (LDS)", src); run<0, 4>("step+test (LDS)", src); run<0, 5>("step+test (LDS)", src); run<0, 6>("step+test (LDS)", src);
+    run<1, 1>("step (LDS)", src); run<1, 2>("step (LDS)", src); run<1, 3>("step (LDS)", src); run<1, 4>("step (LDS)", src); run<1, 5>("step (LDS)", src); run<1, 6>("step (LDS)", src);
+    run<2, 1>("step (registers)", src); run<2, 2>("step (registers)", src); run<2, 3>("step (registers)", src); run<2, 4>("step (registers)", src); run<2, 5>("step (registers)", src); run<2, 6>("step (registers)", src);
+    return 0;
+}

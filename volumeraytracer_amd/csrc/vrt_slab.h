@@ -97,6 +97,30 @@ __device__ __forceinline__ void stat_add(const MarchParams &p, int which, unsign
 #endif
 }
 
+// Development builds with -DVRT_SLAB_PHASES (tools/build_debug.sh, tools/phases.py): every wavefront sums the shader
+// cycles it spends planning / staging / marching from LDS / marching from global memory (s_memtime stamps at phase
+// boundaries, scalar sums) and lane 0 adds them to MarchParams::stats[16..] when the wavefront ends, together with
+// the wave-step counts and a (s_memtime, s_memrealtime) pair that gives the clock the kernel really ran at.
+// Stamps never touch a ray: outputs are unchanged.  Production builds contain none of this.
+#ifdef VRT_SLAB_PHASES
+__device__ __forceinline__ unsigned long long ph_stamp()
+{
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+__device__ __forceinline__ unsigned long long ph_realtime()
+{
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+enum { kPhPlan = 0, kPhStage, kPhLds, kPhDirect, kPhOther, kPhCount };
+#define VRT_PH(i) do { const unsigned long long t_ = ph_stamp(); ph_acc[i] += t_ - ph_t; ph_t = t_; } while (0)
+#else
+#define VRT_PH(i) ((void)0)
+#endif
+
 struct Brick {
     uint32_t lo[3];   // first voxel
     uint32_t e[3];    // extents in voxels
@@ -192,11 +216,17 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
     uint32_t it, rem_w, light;                          // light: brightness, ABSORB only (.cu:332)
     uint32_t slot, ray;
     bool have;
-#ifdef VRT_SLAB_TIMELINE   // development builds: 4 words per wavefront after the 64 counters (tools/timeline.py)
+#if defined(VRT_SLAB_TIMELINE) || defined(VRT_SLAB_PHASES)   // development builds (tools/timeline.py, tools/phases.py)
     uint32_t tl_lds = 0, tl_dir = 0, tl_rounds = 0;
 #define VRT_TL(x) (x)
 #else
 #define VRT_TL(x) ((void)0)
+#endif
+#ifdef VRT_SLAB_PHASES
+    unsigned long long ph_acc[kPhCount] = {0, 0, 0, 0, 0};
+    const unsigned long long ph_t0 = ph_stamp(), ph_r0 = ph_realtime();
+    unsigned long long ph_t = ph_t0;
+    unsigned long long tl_lds_total = 0, tl_dir_total = 0, tl_rounds_total = 0;
 #endif
 
     // march(): advances the wavefront's rays until all of them have stopped
@@ -205,6 +235,7 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
     int32_t sweep_neg[3] = {0, 0, 0}, sweep_pos[3] = {0, 0, 0};
     for (;;) {
         const bool live = it > 0 && in_field(r, bx1, by1, bz1);
+        VRT_PH(kPhOther);
         if (!any_lane(live)) return;             // wave early-out: every lane has terminated
 
         // ---- plan -------------------------------------------------------------------------
@@ -260,6 +291,7 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
             if (v2 <= kCap) { K = K2; vol = v2; bk = b2; }
         }
 
+        VRT_PH(kPhPlan);
         if (vol > kCap || K < kSlabMinK || bk.e[0] < 2 || bk.e[1] < 2 || bk.e[2] < 2) {
             // ---- incoherent wave: gather from global memory for a few steps, then re-plan ----
             stat_add(p, kStatDirectRounds, 1);
@@ -310,6 +342,7 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
 #if VRT_PRIO_DIRECT
             __builtin_amdgcn_s_setprio(0);
 #endif
+            VRT_PH(kPhDirect);
             continue;
         }
 
@@ -349,6 +382,7 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
+        VRT_PH(kPhStage);
 
         // ---- march: up to K steps out of LDS ------------------------------------------------
         {
@@ -417,9 +451,25 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
             if (brick_has_w) run(std::true_type{}); else run(std::false_type{});
             r.px += ox; r.py += oy; r.pz += oz;
         }
+        VRT_PH(kPhLds);
     }
     };  // march
 
+#ifdef VRT_SLAB_PHASES
+    auto ph_flush = [&]() {                              // once per wavefront, after its last group
+        VRT_PH(kPhOther);
+        const unsigned long long r1 = ph_realtime();
+        if (p.stats && lane == 0) {
+            for (int i = 0; i < kPhCount; ++i) atomicAdd(p.stats + 16 + i, ph_acc[i]);
+            atomicAdd(p.stats + 24, 1ull);                                    // wavefronts
+            atomicAdd(p.stats + 25, ph_t - ph_t0);                            // shader cycles (s_memtime)
+            atomicAdd(p.stats + 26, r1 - ph_r0);                              // 100 MHz ticks (s_memrealtime)
+            atomicAdd(p.stats + 27, (unsigned long long)tl_lds_total);
+            atomicAdd(p.stats + 28, (unsigned long long)tl_dir_total);
+            atomicAdd(p.stats + 29, (unsigned long long)tl_rounds_total);
+        }
+    };
+#endif
     auto begin_group = [&](uint32_t first_slot) {        // fill_struct (.cu:468-487): fresh rays from the caller's arrays
         slot = first_slot + lane;
         have = slot < p.nrays;
@@ -439,6 +489,10 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
 #endif
         march();
         if (have) store_ray<DirT>(p, ray, r, rem_w != 0xFFFFFFFFu ? rem_w : it, light);
+#ifdef VRT_SLAB_PHASES
+        tl_lds_total += tl_lds; tl_dir_total += tl_dir; tl_rounds_total += tl_rounds;
+        ph_flush();
+#endif
 #ifdef VRT_SLAB_TIMELINE
         {
             const uint32_t done = have ? p.iterations - (rem_w != 0xFFFFFFFFu ? rem_w : it) : 0u;
@@ -467,6 +521,10 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
 #endif
             march();
             if (have) store_ray<DirT>(p, ray, r, rem_w != 0xFFFFFFFFu ? rem_w : it, light);
+#ifdef VRT_SLAB_PHASES
+            tl_lds_total += tl_lds; tl_dir_total += tl_dir; tl_rounds_total += tl_rounds;
+            tl_lds = tl_dir = tl_rounds = 0;
+#endif
 #ifdef VRT_SLAB_TIMELINE
             {
                 const uint32_t done = have ? p.iterations - (rem_w != 0xFFFFFFFFu ? rem_w : it) : 0u;
@@ -480,6 +538,9 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
             }
 #endif
         }
+#ifdef VRT_SLAB_PHASES
+        ph_flush();
+#endif
     }
 #undef VRT_TL
 }
