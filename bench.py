@@ -117,6 +117,30 @@ def make_rays(cfg, rank, world, band=None, scaling="weak"):
     return gen(cfg["N"], cfg["R"], rows_total=rows, row_range=band if band is not None else D.row_band(rows, rank, world))
 
 
+def build_engine(cfg, dev, log=lambda *a: None):
+    """Field of a bench config resident on `dev` -> (engine, keep-alive objects, bounds, d, tr, lut_host).
+    LUT configs (BASELINE config 5) go through the scene layer (vrt_scene_create_lut): uint8 density + 256-entry transfer
+    function -> int16 field on the device; the march is then run on the scene's engine."""
+    N = cfg["N"]
+    t0 = time.time()
+    if cfg.get("lut"):
+        dens = synth_density_device(N, dev).cpu().numpy()
+        dd = np.arange(256, dtype=np.float64)
+        lut_ior = np.round((1.0 + dd / 510.0) * 65536).astype(np.uint32)
+        lut_tr = np.where(dd < 160, 0xFFFFFFFF, 0).astype(np.uint32)
+        scene = capi.Scene.from_lut([N, N, N], dens, lut_ior, lut_tr)
+        eng = scene.engine()
+        out = (eng, scene, [N - 2] * 3, None, None, (dens, lut_ior, lut_tr))     # lut_host: for the CPU baseline leg only
+    else:
+        bounds, d, tr = synth_field_device(N, cfg["field"], dev, opaque=cfg.get("opaque", False))
+        torch.cuda.synchronize()
+        ftype = capi.VRT_F32 if cfg["field"] == "f32" else capi.VRT_I16
+        eng = capi.Engine.from_device(bounds, [x.data_ptr() for x in d], tr.data_ptr(), ftype, d[0].numel())
+        out = (eng, None, bounds, d, tr, None)
+    log("field %s built on device in %.1f s (%.2f GB resident)" % (cfg["name"], time.time() - t0, eng.field_bytes / 1e9))
+    return out
+
+
 def cpu_baseline(field_host, bounds, sp, sd, inv, iterations, gpu_out, budget_s, log):
     """Time the CPU checker on a bounded sample of this rank's rays (and verify the GPU on it)."""
     import oracle
@@ -231,26 +255,7 @@ def main():
     cfg = CONFIGS[args.config]
     N = cfg["N"]
     scaling = args.scaling if args.scaling != "auto" else ("strong" if args.config == 4 else "weak")
-    t0 = time.time()
-    scene = None
-    if cfg.get("lut"):
-        # BASELINE config 5: uint8 density + 256-entry transfer function -> int16 field, all through the
-        # scene layer (vrt_scene_create_lut); the march is then timed on the scene's engine.
-        dens = synth_density_device(N, dev).cpu().numpy()
-        dd = np.arange(256, dtype=np.float64)
-        lut_ior = np.round((1.0 + dd / 510.0) * 65536).astype(np.uint32)
-        lut_tr = np.where(dd < 160, 0xFFFFFFFF, 0).astype(np.uint32)
-        scene = capi.Scene.from_lut([N, N, N], dens, lut_ior, lut_tr)
-        eng = scene.engine()
-        bounds = [N - 2] * 3
-        d = tr = None
-        lut_host = (dens, lut_ior, lut_tr)                       # kept for the CPU baseline leg only
-    else:
-        bounds, d, tr = synth_field_device(N, cfg["field"], dev, opaque=cfg.get("opaque", False))
-        torch.cuda.synchronize()
-        ftype = capi.VRT_F32 if cfg["field"] == "f32" else capi.VRT_I16
-        eng = capi.Engine.from_device(bounds, [x.data_ptr() for x in d], tr.data_ptr(), ftype, d[0].numel())
-    log("field %s built on device in %.1f s (%.2f GB resident)" % (cfg["name"], time.time() - t0, eng.field_bytes / 1e9))
+    eng, scene, bounds, d, tr, lut_host = build_engine(cfg, dev, log)
 
     inv = [1.0, 1.0, 1.0]
     kern = {"auto": capi.KERNEL_AUTO, "direct": capi.KERNEL_DIRECT, "slab": capi.KERNEL_SLAB}[args.kernel]

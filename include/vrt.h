@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VRT_ABI_VERSION 1
+#define VRT_ABI_VERSION 2
 
 /* element types: DiffType / DirType of the reference's template instantiations
  * (cuda_volume_raytracer.cu:992-1049) */
@@ -68,7 +68,14 @@ typedef struct vrt_options {
                               * can execute this branch; the checker is oracle/vrt_oracle.c's restatement. */
     int32_t  schedule;       /* extension: slab-kernel scheduling. 0 = auto, 1 = static (one wavefront per group of 64
                                 rays, hardware dispatch order), 2 = persistent wavefronts drawing groups from a counter */
-    int32_t  reserved[2];
+    int32_t  devices;        /* extension, read at vrt_create: bit mask of HIP device ordinals the handle spans (bit d = device d),
+                              * 0 = only `device` (default), -1 = every visible device.  The field is replicated on each of
+                              * them, as the reference's constructor does (cuda_volume_raytracer.cu:676-686), and the
+                              * host-pointer calls (vrt_trace) cut the rays into one contiguous band per device, the way
+                              * the reference spreads its chunks over all devices (.cu:804-912).  Device-pointer calls use
+                              * the primary device (`device`, or the lowest bit of the mask when device = -1). */
+    int32_t  host_lanes;     /* extension: chunks a host-pointer call is cut into per device (pipelined over up to 4 streams so
+                              * that uploads and downloads overlap the march), 0 = auto (4 above 2^19 rays, 2 above 2^17, else 1) */
 } vrt_options;
 
 #define VRT_KERNEL_AUTO   0
@@ -121,8 +128,11 @@ int vrt_create_from_device(vrt_handle *out, int dim, const uint16_t *bounds, int
  *   path            NULL, or iterations*3*nrays uint32 laid out as the reference's
  *                   path vector (.cu:791-794, 333-358)
  *   invscale        3 floats
- *   min_brightness  accepted and ignored, as in the reference (.cu:785)
+ *   min_brightness  ignored, as in the reference (.cu:785), unless the opt-in absorption mode is on
+ *                   (vrt_options.absorption), where it is the brightness cut-off of .cu:337-341
  *   iterations      per-ray step cap, must be >= 1
+ * A handle created over several devices (vrt_options.devices) marches one contiguous band of the rays on each.
+ * One call at a time per handle: concurrent calls from several host threads are serialised.
  */
 int vrt_trace(vrt_handle h, int dir_type, size_t nrays,
               const uint32_t *start_pos, const void *start_dir,
@@ -132,8 +142,11 @@ int vrt_trace(vrt_handle h, int dir_type, size_t nrays,
 
 /*
  * Device-pointer form of vrt_trace: every array argument is a DEVICE pointer on the
- * engine's device (invscale stays a host pointer).  Work is enqueued on `stream`
+ * engine's (primary) device (invscale stays a host pointer).  Work is enqueued on `stream`
  * (a hipStream_t, NULL = the null stream) and the call returns without synchronising.
+ * The ray-order and scheduling workspaces belong to the handle, not to the stream: calls issued on
+ * different streams of one handle are ordered one after the other (each waits, on the device, for the
+ * previous call's last kernel), so they are safe but do not overlap; use one handle per stream to overlap.
  */
 int vrt_trace_device(vrt_handle h, int dir_type, size_t nrays,
                      const uint32_t *d_start_pos, const void *d_start_dir,
@@ -152,6 +165,15 @@ const void *vrt_engine_field_device_ptr(vrt_handle h);
  * from HIP events recorded on the launch stream around the kernel (waits for it to finish).
  * Negative if nothing has been launched.  Used by bench.py for the roofline figure. */
 float vrt_engine_last_march_ms(vrt_handle h);
+/* Shader clock, in GHz, that the most recent march kernel really ran at: one of its wavefronts reads s_memtime and
+ * s_memrealtime when it starts and when it ends.  Negative if unavailable.  The roofline's VALU-issue peak is
+ * SIMDs x this clock / 2 (bench.py). */
+float vrt_engine_last_march_clock_ghz(vrt_handle h);
+/* Number of devices (engines) behind a handle: 1 + replicas made for vrt_options.devices. */
+int vrt_engine_replica_count(vrt_handle h);
+/* The contiguous cut of n rays into `parts` bands that multi-device handles and the chunk pipeline use
+ * (begin[0..parts], whole groups of 64 rays where possible).  Exposed for tests. */
+int vrt_debug_band_cut(size_t n, size_t parts, size_t *begin);
 /* Development aid: with VRT_DEBUG_STATS=1 in the environment the slab kernel counts planning
  * rounds / staged voxels / LDS steps; this copies up to n counters of the last launch (64 counters, then,
  * in -DVRT_SLAB_TIMELINE development builds, a begin/end clock pair per wavefront). */
@@ -210,6 +232,20 @@ int vrt_scene_trace(vrt_scene_handle s, int dir_type, size_t nrays, const uint32
                     uint32_t *end_pos, void *end_dir, uint32_t *end_iter, uint32_t *remaining_light,
                     uint32_t *path, const float *invscale, uint32_t min_brightness, uint32_t iterations,
                     int normalize_length, const vrt_options *opt);
+
+/*
+ * Device-pointer form of vrt_scene_trace ("lets Python pass device buffers"): all ray arrays are DEVICE
+ * pointers on the scene's device, the ray front end, the march and the +0x10000 epilogue are enqueued on `stream`
+ * and the call returns without synchronising.  The start arrays are not modified.  Range / normalisation errors of
+ * the rays cannot be known when the call returns: vrt_scene_trace_status() waits for the call and reports them.
+ */
+int vrt_scene_trace_device(vrt_scene_handle s, int dir_type, size_t nrays, const uint32_t *d_start_pos,
+                           const void *d_start_dir, uint32_t *d_end_pos, void *d_end_dir, uint32_t *d_end_iter,
+                           uint32_t *d_remaining_light, uint32_t *d_path, const float *invscale,
+                           uint32_t min_brightness, uint32_t iterations, void *stream, const vrt_options *opt);
+/* Waits for the most recent vrt_scene_trace_device call of the scene and returns VRT_OK, VRT_ERR_RAY_RANGE
+ * ("ray i is not in 0 to ...", image_util.cpp:690-695) or VRT_ERR_SCENE ("Normalize length failed", :705-708). */
+int vrt_scene_trace_status(vrt_scene_handle s);
 
 /* Replaces RaytraceScene::~RaytraceScene (image_util.cpp:774-778). */
 void vrt_scene_destroy(vrt_scene_handle s);

@@ -34,9 +34,15 @@ TraceRaysCu<DiffType>::TraceRaysCu(std::vector<size_t> const &bounds, std::vecto
     for (size_t b : bounds) _output_sizes.push_back(static_cast<uint16_t>(b));
     std::vector<const void *> d;
     for (auto const *v : diff) d.push_back(v->data());
+    // the reference replicates the field on every CUDA device (cuda_volume_raytracer.cu:676-686) and trace_rays_cu spreads
+    // its chunks over all of them (:804-912): the handle spans every visible device and vrt_trace cuts the rays into
+    // one band per device (calls with no more than Options::_minimum_gpu rays stay on one, as :805 keeps them on the CPU)
+    vrt_options o;
+    vrt_options_default(&o);
+    o.devices = -1;
     vrt_handle h = nullptr;
     check(vrt_create(&h, static_cast<int>(bounds.size()), _output_sizes.data(), elem<DiffType>::value, d.data(),
-                     translucency_cropped.data(), translucency_cropped.size(), nullptr));
+                     translucency_cropped.data(), translucency_cropped.size(), &o));
     _tex = h;
 }
 

@@ -30,12 +30,27 @@ def test_header_symbols_exported():
 
 def test_abi_version_and_options_layout():
     lib = capi.load()
-    assert lib.vrt_abi_version() == 1
+    assert lib.vrt_abi_version() == 2
     o = capi.default_options()
     # struct Options defaults, /root/reference/src/types.h:90
     assert (o.loglevel, o.minimum_gpu, o.write_instance, o.max_cpu) == (0, 0x80, 0, 256)
     assert o.device == -1 and o.kernel == capi.KERNEL_AUTO
     assert ctypes.sizeof(capi.Options) == 64
+    assert (o.devices, o.host_lanes) == (0, 0)           # extensions default off: one device, auto chunking
+
+
+def test_band_cut():
+    """The contiguous cut multi-device handles and the chunk pipeline use (pure host arithmetic): covers all rays once, in order,
+    whole groups of 64 except at the very end, sizes within one group of each other."""
+    for n in (0, 1, 63, 64, 65, 1000, 4096, 100003, 1 << 20):
+        for parts in (1, 2, 3, 4, 7, 8):
+            b = capi.band_cut(n, parts)
+            assert len(b) == parts + 1 and b[0] == 0 and b[-1] == n
+            assert all(b[k] <= b[k + 1] for k in range(parts))
+            assert all(b[k] % 64 == 0 for k in range(parts) if b[k] < n)
+            sizes = [b[k + 1] - b[k] for k in range(parts)]
+            full = [x for x in sizes[:-1] if x > 0] or [0]
+            assert max(full) - min(full) <= 64
 
 
 def test_argument_validation_without_gpu():

@@ -1,0 +1,174 @@
+"""GPU (-m gpu): the engine object behind the C ABI beyond a single plain call -- the things the reference's
+dispatcher does around the march (cuda_volume_raytracer.cu:676-686 replicate, :804-912 chunk fan-out over devices)
+and what the MI355X engine adds (streams, chunk pipeline, device-pointer scene entry).  Every variant must give the
+bits of the plain single call, which test_gpu_parity.py pins to the oracle and the reference's golden vectors; the
+plain call is pinned to the oracle here once more so that this file stands on its own."""
+import numpy as np
+import pytest
+
+import oracle
+from volumeraytracer_amd import capi, workloads as W
+
+pytestmark = pytest.mark.gpu
+KEYS = ("end_position", "end_direction", "end_iteration", "remaining_light")
+
+
+def _same(a, b):
+    return a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+def _scene(N=56, fdt=np.float32, ddt=np.float32, nrays=20000, opaque=4.0):
+    bounds, dx, dy, dz, tc = W.seam_field(N, fdt, seed=31, opaque_radius=opaque)
+    sp, sd = W.random_rays(N, nrays, ddt, seed=99, vol_seed=31)
+    field = oracle.port.interleave(dx, dy, dz, tc)
+    want = oracle.port.trace(field, bounds, sp, sd, [1, 1, 1], 100000)
+    return bounds, (dx, dy, dz), tc, sp, sd, want
+
+
+def test_two_streams_one_engine():
+    """Two device-pointer calls in flight on two streams of ONE handle (different ray sets, so a shared permutation or
+    group counter would show): the handle's workspaces are per handle, the second call must wait for the first on the
+    device (vrt.h, vrt_trace_device) -- both results equal the oracle."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    bounds, d, tc, sp, sd, want = _scene(nrays=40000)
+    half = (sp.size // 3 // 2) * 3
+    sets = [(sp[:half], sd[:half]), (sp[half:], sd[half:])]
+    with capi.Engine.from_host(bounds, list(d), tc) as eng:
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        outs = []
+        for rep in range(3):                                   # back to back, alternating streams, nothing synchronised between
+            for (p, q), st in zip(sets, streams):
+                n = p.size // 3
+                t_sp = torch.from_numpy(p.view(np.int32)).to(dev)
+                t_sd = torch.from_numpy(q).to(dev)
+                o = [torch.empty(3 * n, dtype=torch.int32, device=dev), torch.empty(3 * n, dtype=torch.float32, device=dev),
+                     torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev)]
+                torch.cuda.synchronize()
+                outs.append((o, t_sp, t_sd, n))
+        k = 0
+        for rep in range(3):
+            for st in streams:
+                o, t_sp, t_sd, n = outs[k]
+                k += 1
+                eng.trace_device(capi.VRT_F32, n, t_sp.data_ptr(), t_sd.data_ptr(), o[0].data_ptr(), o[1].data_ptr(),
+                                 o[2].data_ptr(), o[3].data_ptr(), [1, 1, 1], 100000, stream=st.cuda_stream,
+                                 options=capi.default_options(kernel=capi.KERNEL_SLAB, sort_rays=3, schedule=2))
+        torch.cuda.synchronize()
+        n0 = half // 3
+        for k, (o, _, _, n) in enumerate(outs):
+            sl = slice(0, n0) if k % 2 == 0 else slice(n0, None)
+            assert np.array_equal(o[0].cpu().numpy().view(np.uint32).reshape(-1, 3), want["end_position"].reshape(-1, 3)[sl]), k
+            assert np.array_equal(o[1].cpu().numpy().view(np.uint32).reshape(-1, 3),
+                                  want["end_direction"].view(np.uint32).reshape(-1, 3)[sl]), k
+            assert np.array_equal(o[2].cpu().numpy().view(np.uint32), want["end_iteration"][sl]), k
+
+
+@pytest.mark.parametrize("fdt,ddt", [(np.float32, np.float32), (np.int16, np.int16)])
+def test_host_chunk_pipeline(fdt, ddt):
+    """vrt_trace cut into 1, 2, 4 and 7 chunks pipelined over the engine's lanes: same bits, whatever the cut."""
+    bounds, d, tc, sp, sd, want = _scene(fdt=fdt, ddt=ddt, nrays=30011)
+    with capi.Engine.from_host(bounds, list(d), tc) as eng:
+        for lanes in (1, 2, 4, 7):
+            got = eng.trace(sp, sd, [1, 1, 1], 100000, options=capi.default_options(host_lanes=lanes))
+            for k in KEYS:
+                assert _same(got[k], want[k]), (lanes, k)
+
+
+def test_multi_engine_handle_on_one_device(monkeypatch):
+    """The multi-device path of a handle (field replicated, one contiguous band of rays per engine, results written
+    straight into the caller's arrays) with all engines on device 0 (VRT_DEBUG_REPLICAS): band cut + merge must
+    reproduce the single-engine result bit for bit.  A one-bit device mask is today's single-device handle."""
+    bounds, d, tc, sp, sd, want = _scene(nrays=25013)
+    monkeypatch.setenv("VRT_DEBUG_REPLICAS", "3")
+    with capi.Engine.from_host(bounds, list(d), tc) as eng:
+        assert eng.replica_count == 3
+        got = eng.trace(sp, sd, [1, 1, 1], 100000)
+        for k in KEYS:
+            assert _same(got[k], want[k]), k
+        few = eng.trace(sp[:3 * 50], sd[:3 * 50], [1, 1, 1], 100000)         # fewer rays than engines x 64: one band
+        assert _same(few["end_iteration"], want["end_iteration"][:50])
+        assert _same(few["end_position"], want["end_position"][:150]) and _same(few["end_direction"], want["end_direction"][:150])
+        pth = eng.trace(sp[:3 * 300], sd[:3 * 300], [1, 1, 1], 37, trace_paths=True)
+    monkeypatch.delenv("VRT_DEBUG_REPLICAS")
+    with capi.Engine.from_host(bounds, list(d), tc, options=capi.default_options(devices=1)) as eng1:
+        assert eng1.replica_count == 1
+        got = eng1.trace(sp, sd, [1, 1, 1], 100000)
+        for k in KEYS:
+            assert _same(got[k], want[k]), k
+        pth1 = eng1.trace(sp[:3 * 300], sd[:3 * 300], [1, 1, 1], 37, trace_paths=True)
+    for k in KEYS + ("path",):
+        assert _same(pth[k], pth1[k]), k
+    with capi.Engine.from_host(bounds, list(d), tc, options=capi.default_options(devices=-1)) as eng_all:
+        assert eng_all.replica_count == capi.device_count()                   # every visible device (1 on the test box)
+        got = eng_all.trace(sp, sd, [1, 1, 1], 100000)
+        for k in KEYS:
+            assert _same(got[k], want[k]), k
+
+
+@pytest.mark.parametrize("dti,dtd", [(np.float32, np.float32), (np.uint32, np.int16)])
+def test_scene_device_entry(dti, dtd):
+    """vrt_scene_trace_device (device buffers, asynchronous) == vrt_scene_trace (host buffers) == the oracle's scene
+    layer; the caller's start arrays are left untouched; a ray outside the volume surfaces in status()."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    N = 40
+    ior = W.ior_volume(N, seed=9, dtype=dti).reshape(-1)
+    rng = np.random.RandomState(5)
+    tr = np.full(N ** 3, 0xFFFFFFFF, np.uint32)
+    tr[rng.rand(N ** 3) < 0.01] = 7
+    n = 5000
+    pv = 1.0 + rng.rand(n, 3) * (N - 2.001)
+    sp = np.round(pv * 65536).astype(np.uint32).reshape(-1)
+    dd = rng.randn(n, 3)
+    dd /= np.linalg.norm(dd, axis=1)[:, None]
+    sd = dd.astype(np.float32).reshape(-1) if dtd == np.float32 else np.round(dd * 256).astype(np.int16).reshape(-1)
+    want = oracle.port.scene_trace([N] * 3, ior, tr, sp, sd, [1, 1, 1], 100000)
+    dtype = capi.VRT_F32 if dtd == np.float32 else capi.VRT_I16
+    with capi.Scene([N] * 3, ior, tr) as sc:
+        host = sc.trace_rays(sp, sd, [1, 1, 1], 100000)
+        for k in KEYS:
+            assert _same(host[k], want[k]), k
+        t_sp = torch.from_numpy(sp.view(np.int32)).to(dev)
+        t_sd = torch.from_numpy(sd).to(dev)
+        ep = torch.empty(3 * n, dtype=torch.int32, device=dev)
+        ed = torch.empty(3 * n, dtype=t_sd.dtype, device=dev)
+        ei = torch.empty(n, dtype=torch.int32, device=dev)
+        rl = torch.empty(n, dtype=torch.int32, device=dev)
+        st = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        sc.trace_rays_device(dtype, n, t_sp.data_ptr(), t_sd.data_ptr(), ep.data_ptr(), ed.data_ptr(), ei.data_ptr(),
+                             rl.data_ptr(), [1, 1, 1], 100000, stream=st.cuda_stream)
+        sc.status()
+        assert np.array_equal(ep.cpu().numpy().view(np.uint32), want["end_position"])
+        assert _same(ed.cpu().numpy(), want["end_direction"])
+        assert np.array_equal(ei.cpu().numpy().view(np.uint32), want["end_iteration"])
+        assert np.array_equal(rl.cpu().numpy().view(np.uint32), want["remaining_light"])
+        assert np.array_equal(t_sp.cpu().numpy().view(np.uint32), sp) and _same(t_sd.cpu().numpy(), sd)
+        bad = sp.copy()
+        bad[3 * 17] = 0x8000                                        # ray 17 below 1.0 (image_util.cpp:690-695)
+        t_bad = torch.from_numpy(bad.view(np.int32)).to(dev)
+        sc.trace_rays_device(dtype, n, t_bad.data_ptr(), t_sd.data_ptr(), ep.data_ptr(), ed.data_ptr(), ei.data_ptr(),
+                             rl.data_ptr(), [1, 1, 1], 100000, stream=st.cuda_stream)
+        with pytest.raises(capi.VrtError) as e:
+            sc.status()
+        assert e.value.code == -7 and "ray 17 " in str(e.value)
+        sc.status()                                                 # reported once
+
+
+def test_march_clock_is_reported():
+    bounds, d, tc, sp, sd, want = _scene(nrays=8192)
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    n = sp.size // 3
+    with capi.Engine.from_host(bounds, list(d), tc) as eng:
+        t_sp = torch.from_numpy(sp.view(np.int32)).to(dev)
+        t_sd = torch.from_numpy(sd).to(dev)
+        o = [torch.empty(3 * n, dtype=torch.int32, device=dev), torch.empty(3 * n, dtype=torch.float32, device=dev),
+             torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev)]
+        eng.trace_device(capi.VRT_F32, n, t_sp.data_ptr(), t_sd.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(),
+                         o[3].data_ptr(), [1, 1, 1], 100000, options=capi.default_options(kernel=capi.KERNEL_SLAB))
+        torch.cuda.synchronize()
+        ghz = eng.last_march_clock_ghz()
+        assert 0.3 < ghz < 3.0, ghz
+        assert np.array_equal(o[2].cpu().numpy().view(np.uint32), want["end_iteration"])

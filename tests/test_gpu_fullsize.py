@@ -63,3 +63,68 @@ def test_config3_full_size_properties():
     assert np.array_equal(want["end_direction"].view(np.uint32).reshape(-1, 3), ed.view(np.uint32).reshape(-1, 3)[idx])
     assert np.array_equal(want["end_iteration"], ei.view(np.uint32)[idx])
     eng.close()
+
+
+def test_config4_tiled():
+    """BASELINE config 4 as written: 512^3 fp32 field, 2048 x 2048 perspective rays cut into 8 contiguous row bands
+    (the tiles the 8 GPUs of a node would take, distributed.row_band).  On the one GPU here every band is marched into
+    its own output record, the records are reassembled exactly as rank 0 does after the gather
+    (distributed.assemble), and the result must equal the single launch over all 4 194 304 rays bit for bit.
+    An evenly strided sample is checked against the oracle and every ray must have left the field."""
+    torch = pytest.importorskip("torch")
+    import bench
+    cfg = bench.CONFIGS[4]
+    world = 8
+    dev = torch.device("cuda", 0)
+    bounds, d, tr = bench.synth_field_device(cfg["N"], cfg["field"], dev)
+    torch.cuda.synchronize()
+    eng = capi.Engine.from_device(bounds, [x.data_ptr() for x in d], tr.data_ptr(), capi.VRT_F32, d[0].numel())
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def march(sp, sd):
+        n = sp.size // 3
+        d_sp = torch.from_numpy(sp.view(np.int32)).to(dev)
+        d_sd = torch.from_numpy(sd).to(dev)
+        rec = D.alloc_record(n, dev)
+        ep, ed, ei, rl = D.record_views(rec, n)
+        eng.trace_device(capi.VRT_F32, n, d_sp.data_ptr(), d_sd.data_ptr(), ep.data_ptr(), ed.data_ptr(), ei.data_ptr(),
+                         rl.data_ptr(), [1, 1, 1], 100000, stream=stream)
+        torch.cuda.synchronize()
+        return rec
+
+    assert bench.lattice_rows(cfg, world, "strong") == 2048            # the fixed lattice, not 8 x 2048 rows
+    sp_all, sd_all = bench.make_rays(cfg, 0, 1, scaling="strong")
+    n_all = sp_all.size // 3
+    assert n_all == 2048 * 2048
+    whole = D.assemble([march(sp_all, sd_all)], [n_all])
+
+    records, counts, first = [], [], 0
+    for rank in range(world):
+        sp, sd = bench.make_rays(cfg, rank, world, scaling="strong")
+        n = sp.size // 3
+        assert np.array_equal(sp, sp_all[3 * first:3 * (first + n)]) and np.array_equal(sd, sd_all[3 * first:3 * (first + n)])
+        records.append(march(sp, sd))
+        counts.append(n)
+        first += n
+    assert first == n_all and len(set(counts)) == 1
+    tiled = D.assemble(records, counts)
+    for k in ("end_position", "end_direction_bits", "end_iteration", "remaining_light"):
+        assert np.array_equal(tiled[k], whole[k]), "8 row bands vs one launch: %s" % k
+
+    assert np.all(whole["remaining_light"] == 0xFFFFFFFF)
+    steps = whole["end_iteration"].astype(np.int64)
+    assert steps.min() > 500 and steps.max() < 100000
+    B = np.array(bounds, np.int64)
+    cell = whole["end_position"].reshape(-1, 3).astype(np.int64) >> 16
+    assert np.all(np.any((cell >= B - 1) | (cell > 60000), axis=1)), "every ray ended outside the field"
+
+    host = [x.cpu().numpy() for x in d]
+    field = oracle.port.interleave(host[0], host[1], host[2], tr.cpu().numpy().view(np.uint32))
+    del host
+    idx = np.linspace(0, n_all - 1, 3000).astype(np.int64)
+    want = oracle.port.trace(field, bounds, sp_all.reshape(-1, 3)[idx].reshape(-1), sd_all.reshape(-1, 3)[idx].reshape(-1),
+                             [1, 1, 1], 100000)
+    assert np.array_equal(want["end_position"].reshape(-1, 3), whole["end_position"].reshape(-1, 3)[idx])
+    assert np.array_equal(want["end_direction"].view(np.uint32).reshape(-1, 3), whole["end_direction_bits"].reshape(-1, 3)[idx])
+    assert np.array_equal(want["end_iteration"], whole["end_iteration"][idx])
+    eng.close()

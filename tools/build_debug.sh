@@ -9,6 +9,6 @@ mkdir -p tmp_libs
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-slp-vectorize -DVRT_SLAB_TIMELINE \
     -o tmp_libs/libvrt_timeline.so volumeraytracer_amd/csrc/vrt_engine.hip
 echo tmp_libs/libvrt_stats.so tmp_libs/libvrt_timeline.so
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-slp-vectorize -DVRT_SLAB_PHASES \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-slp-vectorize -DVRT_SLAB_PHASES $VRT_EXTRA_DEFS \
     -o tmp_libs/libvrt_phases.so volumeraytracer_amd/csrc/vrt_engine.hip
 echo tmp_libs/libvrt_phases.so

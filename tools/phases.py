@@ -27,17 +27,7 @@ def main():
     args = ap.parse_args()
     cfg = bench.CONFIGS[args.config]
     dev = torch.device("cuda:0")
-    if cfg.get("lut"):
-        N = cfg["N"]
-        dens = bench.synth_density_device(N, dev).cpu().numpy()
-        dd = np.arange(256, dtype=np.float64)
-        scene = capi.Scene.from_lut([N, N, N], dens, np.round((1.0 + dd / 510.0) * 65536).astype(np.uint32),
-                                    np.where(dd < 160, 0xFFFFFFFF, 0).astype(np.uint32))
-        eng = scene.engine()
-    else:
-        bounds, d, tr = bench.synth_field_device(cfg["N"], cfg["field"], dev, opaque=cfg.get("opaque", False))
-        ftype = capi.VRT_F32 if cfg["field"] == "f32" else capi.VRT_I16
-        eng = capi.Engine.from_device(bounds, [x.data_ptr() for x in d], tr.data_ptr(), ftype, d[0].numel())
+    eng, scene, bounds, d, tr, _ = bench.build_engine(cfg, dev)
     sp, sd = bench.make_rays(cfg, 0, 1)
     n = sp.size // 3
     d_sp = torch.from_numpy(sp.view(np.int32)).to(dev)

@@ -20,6 +20,8 @@ ABI_SYMBOLS = (
     "vrt_trace", "vrt_trace_device", "vrt_destroy", "vrt_engine_device", "vrt_engine_field_bytes",
     "vrt_engine_field_device_ptr", "vrt_engine_last_march_ms", "vrt_engine_debug_stats", "vrt_selftest_ilen2",
     "vrt_last_error", "vrt_scene_create", "vrt_scene_create_lut", "vrt_scene_trace", "vrt_scene_destroy", "vrt_scene_engine",
+    "vrt_engine_last_march_clock_ghz", "vrt_engine_replica_count", "vrt_debug_band_cut", "vrt_scene_trace_device",
+    "vrt_scene_trace_status",
 )
 
 
@@ -35,7 +37,7 @@ class Options(C.Structure):
     """struct vrt_options == the reference's struct Options (types.h:83-91) + extensions."""
     _fields_ = [("loglevel", C.c_int32), ("minimum_gpu", C.c_uint64), ("write_instance", C.c_int32),
                 ("max_cpu", C.c_uint64), ("device", C.c_int32), ("kernel", C.c_int32),
-                ("sort_rays", C.c_int32), ("slab_lds_bytes", C.c_int32), ("absorption", C.c_int32), ("schedule", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("sort_rays", C.c_int32), ("slab_lds_bytes", C.c_int32), ("absorption", C.c_int32), ("schedule", C.c_int32), ("devices", C.c_int32), ("host_lanes", C.c_int32)]
 
 
 _lib = None
@@ -89,6 +91,14 @@ def load():
         L.vrt_selftest_ilen2.argtypes = [C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     L.vrt_engine_last_march_ms.argtypes = [vp]
     L.vrt_engine_last_march_ms.restype = C.c_float
+    if hasattr(L, "vrt_engine_last_march_clock_ghz"):
+        L.vrt_engine_last_march_clock_ghz.argtypes = [vp]
+        L.vrt_engine_last_march_clock_ghz.restype = C.c_float
+        L.vrt_engine_replica_count.argtypes = [vp]
+        L.vrt_debug_band_cut.argtypes = [sz, sz, C.POINTER(C.c_size_t)]
+        L.vrt_scene_trace_device.argtypes = [vp, C.c_int, sz, u32p, vp, u32p, vp, u32p, u32p, u32p, vp, C.c_uint32,
+                                             C.c_uint32, vp, C.POINTER(Options)]
+        L.vrt_scene_trace_status.argtypes = [vp]
     if hasattr(L, "vrt_scene_create"):
         L.vrt_scene_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_size_t), C.c_int, vp, u32p, sz,
                                        C.POINTER(Options)]
@@ -119,6 +129,13 @@ def default_options(**kw):
 
 def device_count():
     return int(load().vrt_device_count())
+
+
+def band_cut(n, parts):
+    """The contiguous cut of n rays into `parts` bands used by multi-device handles and the chunk pipeline."""
+    b = (C.c_size_t * (int(parts) + 1))()
+    check(load().vrt_debug_band_cut(int(n), int(parts), b))
+    return [int(x) for x in b]
 
 
 def selftest_ilen2(device=0):
@@ -201,12 +218,21 @@ class Engine:
         buf = (C.c_ulonglong * 16)()
         check(load().vrt_engine_debug_stats(self._h, buf, 16))
         names = ("rounds", "planned_K_sum", "lds_wave_steps", "direct_rounds", "direct_wave_steps", "vox_staged",
-                 "early_exit", "_7", "fb_ex_sum", "fb_ey_sum", "fb_ez_sum", "fb_live_lanes_sum", "fb_steps_done_sum")
+                 "early_exit", "proven_rounds", "fb_ex_sum", "fb_ey_sum", "fb_ez_sum", "fb_live_lanes_sum", "fb_steps_done_sum", "proven_steps")
         return dict(zip(names, [int(x) for x in buf]))
 
     def last_march_ms(self):
         """HIP-event duration of the most recent march kernel (waits for it)."""
         return float(load().vrt_engine_last_march_ms(self._h))
+
+    def last_march_clock_ghz(self):
+        """Shader clock the most recent march kernel ran at (s_memtime / s_memrealtime of one of its wavefronts)."""
+        return float(load().vrt_engine_last_march_clock_ghz(self._h))
+
+    @property
+    def replica_count(self):
+        """Devices (engines) behind the handle: 1 + replicas made for options.devices."""
+        return int(load().vrt_engine_replica_count(self._h))
 
     def trace(self, start_pos, start_dir, invscale, iterations, trace_paths=False, min_brightness=0, options=None):
         """vrt_trace on host numpy arrays; returns dict of numpy outputs."""
@@ -332,6 +358,23 @@ class Scene:
                                 int(minimum_brightness), int(iterations), 1 if normalize_length else 0,
                                 C.byref(options) if options is not None else None))
         return dict(end_position=ep, end_direction=ed, end_iteration=ei, remaining_light=rl, path=path)
+
+    def trace_rays_device(self, dir_type, nrays, d_start_pos, d_start_dir, d_end_pos, d_end_dir, d_end_iter,
+                          d_remaining_light, invscale, iterations, d_path=0, stream=0, minimum_brightness=0, options=None):
+        """vrt_scene_trace_device on raw device pointers (ints); asynchronous on `stream`.  Ray errors surface in
+        status()."""
+        L = load()
+        inv = np.ascontiguousarray(invscale, dtype=np.float32)
+        check(L.vrt_scene_trace_device(self._h, dir_type, int(nrays), C.c_void_p(int(d_start_pos)),
+                                       C.c_void_p(int(d_start_dir)), C.c_void_p(int(d_end_pos)), C.c_void_p(int(d_end_dir)),
+                                       C.c_void_p(int(d_end_iter)), C.c_void_p(int(d_remaining_light)),
+                                       C.c_void_p(int(d_path)) if d_path else None, _np_ptr(inv), int(minimum_brightness),
+                                       int(iterations), C.c_void_p(int(stream)) if stream else None,
+                                       C.byref(options) if options is not None else None))
+
+    def status(self):
+        """Wait for the last trace_rays_device call and raise its ray error, if any."""
+        check(load().vrt_scene_trace_status(self._h))
 
     def close(self):
         if self._h is not None and _lib is not None:

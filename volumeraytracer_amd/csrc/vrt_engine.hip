@@ -24,7 +24,10 @@
 #include "vrt_sort.h"
 #include "vrt_scene.h"
 
+#include <dlfcn.h>
+
 #include <cmath>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include <atomic>
@@ -77,6 +80,53 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// roctx ranges ("roctx ranges around upload/kernel/gather") so that a rocprofv3 --marker-trace timeline
+// of a call reads upload / ray order / march / download.  The marker library is looked up at run time: it is
+// present under a profiler and otherwise not needed, and the engine must not depend on it.
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        if (const char *off = getenv("VRT_NO_ROCTX"); off && off[0] == '1') return;
+        for (const char *name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            if (void *h = dlopen(name, RTLD_LAZY | RTLD_LOCAL)) {
+                push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+                pop = (int (*)())dlsym(h, "roctxRangePop");
+                if (push && pop) return;
+                push = nullptr; pop = nullptr;
+            }
+        }
+    }
+};
+const Roctx &roctx() { static Roctx r; return r; }
+struct Range {
+    bool on;
+    explicit Range(const char *name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+    ~Range() { if (on) roctx().pop(); }
+};
+
+// Everything one in-flight trace call needs besides the field.  An engine owns kLanes of them: lane 0 serves the
+// device-pointer entry points (any caller stream; calls on different streams are ordered by ev_done), all lanes serve
+// the host-pointer entry points, whose chunks are pipelined over the lanes' own streams.
+struct Workspace {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;   // around the most recent march kernel of this lane
+    hipEvent_t ev_done = nullptr;                      // after the last launch that used these buffers
+    bool ev_valid = false, used = false;
+    DevBuf sort_keys, sort_keys_alt, sort_vals, sort_vals_alt, sort_tmp, sort_bounds;
+    DevBuf group_ctr;              // group counter of the persistent slab kernel (vrt_options.schedule)
+    DevBuf clock;                  // (s_memtime, s_memrealtime) at the start and end of one wavefront of the march
+    DevBuf stats;                  // debug counters, allocated only when VRT_DEBUG_STATS=1
+    size_t stats_count = 0;
+    DevBuf in_pos, in_dir, out_pos, out_dir, out_iter, out_light, path;   // device staging of host-pointer calls
+    DevBuf pro_pos, pro_dir, err;  // scene layer: prologue outputs of device-pointer calls, error words
+    void *pin_err = nullptr;       // pinned host copy of the error words (scene layer)
+    DevBuf *all[18] = {&sort_keys, &sort_keys_alt, &sort_vals, &sort_vals_alt, &sort_tmp, &sort_bounds, &group_ctr, &clock,
+                       &stats, &in_pos, &in_dir, &out_pos, &out_dir, &out_iter, &out_light, &path, &pro_pos, &pro_dir};
+};
+constexpr int kLanes = 4;
+
 }  // namespace
 
 struct vrt_engine {
@@ -86,17 +136,14 @@ struct vrt_engine {
     size_t nvox = 0;
     void *field = nullptr;         // interleaved AoS field, resident for the engine's lifetime
     size_t field_bytes = 0;
-    hipStream_t stream = nullptr;  // used by the host-pointer entry point
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr;   // around the most recent march kernel
-    bool ev_valid = false;
     int num_cu = 256;
-    // workspaces (grow-only; no allocation in steady state)
-    DevBuf sort_keys, sort_keys_alt, sort_vals, sort_vals_alt, sort_tmp, sort_bounds;
+    float gmax[3] = {INFINITY, INFINITY, INFINITY};   // max |field channel| over the whole field (proven rounds, vrt_slab.h: safe_steps)
     DevBuf transl;                 // translucency per field voxel, kept only for the opt-in absorption mode
-    DevBuf group_ctr;                  // group counter of the persistent slab kernel (vrt_options.schedule)
-    DevBuf stats;                  // debug counters, allocated only when VRT_DEBUG_STATS=1
-    size_t stats_count = 0;
-    DevBuf h_in_pos, h_in_dir, h_out_pos, h_out_dir, h_out_iter, h_out_light, h_path;
+    Workspace ws[kLanes];
+    std::mutex mu;                 // device-pointer calls: one host thread at a time inside an engine
+    // multi-device handles (vrt_options.devices): the field replicated on other devices, as the reference's ctor does
+    // (cuda_volume_raytracer.cu:676-686); host-pointer calls cut the rays into one contiguous band per device.
+    std::vector<vrt_engine *> replicas;
     vrt_options opt;
 };
 
@@ -148,6 +195,45 @@ int launch_interleave(vrt_engine *e, const void *const d_diff[3], const uint32_t
     return VRT_OK;
 }
 
+// ---- per-channel max |value| of the interleaved field (one pass at create; feeds MarchParams::gstep) -------------
+// Non-negative floats order like their bit patterns, and a NaN's pattern is above infinity's: an atomic max on the
+// patterns of |v| returns the largest magnitude, or a NaN if the field holds one (which then disables proven rounds).
+template <typename VoxT>
+__global__ __launch_bounds__(256) void k_field_absmax(const VoxT *f, size_t n, uint32_t *out /* [3] */)
+{
+    uint32_t m[3] = {0u, 0u, 0u};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const VoxT v = f[i];
+        const float a[3] = {(float)v.x, (float)v.y, (float)v.z};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { const uint32_t b = __float_as_uint(a[d]) & 0x7FFFFFFFu; m[d] = b > m[d] ? b : m[d]; }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)m[d], o); m[d] = t > m[d] ? t : m[d]; }
+        if ((threadIdx.x & 63u) == 0) atomicMax(&out[d], m[d]);
+    }
+}
+
+int engine_field_absmax(vrt_engine *e, hipStream_t s)
+{
+    uint32_t *d_out = nullptr, h[3] = {0, 0, 0};
+    HIP_TRY(hipMalloc(&d_out, sizeof h));
+    hipError_t err = hipMemsetAsync(d_out, 0, sizeof h, s);
+    if (err == hipSuccess) {
+        const int grid = (int)std::min<size_t>((e->nvox + 255) / 256, (size_t)e->num_cu * 8);
+        if (e->field_type == VRT_F32) k_field_absmax<<<grid, 256, 0, s>>>((const vrt::vox_f32 *)e->field, e->nvox, d_out);
+        else                          k_field_absmax<<<grid, 256, 0, s>>>((const vrt::vox_i16 *)e->field, e->nvox, d_out);
+        err = hipGetLastError();
+    }
+    if (err == hipSuccess) err = hipMemcpyAsync(h, d_out, sizeof h, hipMemcpyDeviceToHost, s);
+    if (err == hipSuccess) err = hipStreamSynchronize(s);
+    (void)hipFree(d_out);
+    HIP_TRY(err);
+    memcpy(e->gmax, h, sizeof h);
+    return VRT_OK;
+}
+
 int check_create_args(vrt_handle *out, int dim, const uint16_t *bounds, int field_type, const void *const *diff,
                       const uint32_t *tr, size_t nvox)
 {
@@ -176,6 +262,10 @@ int engine_alloc(vrt_engine **pe, const uint16_t *bounds, int field_type, size_t
     if (!e) return fail(VRT_ERR_OUT_OF_MEMORY, "host allocation failed");
     if (opt) e->opt = *opt; else vrt_options_default(&e->opt);
     int dev = e->opt.device;
+    if (e->opt.devices == -1) e->opt.devices = (int32_t)(ndev >= 32 ? 0xFFFFFFFFu : ((1u << ndev) - 1u));
+    if (dev < 0 && e->opt.devices != 0) {                // no primary named: the lowest device of the mask
+        for (int d = 0; d < 32; ++d) if ((uint32_t)e->opt.devices >> d & 1u) { dev = d; break; }
+    }
     if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
     if (dev >= ndev) { delete e; return fail(VRT_ERR_INVALID_ARGUMENT, "device %d out of range (%d devices)", dev, ndev); }
     e->device = dev;
@@ -187,33 +277,47 @@ int engine_alloc(vrt_engine **pe, const uint16_t *bounds, int field_type, size_t
     return VRT_OK;
 }
 
+int workspace_init(Workspace &w)
+{
+    HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&w.ev_begin));
+    HIP_TRY(hipEventCreate(&w.ev_end));
+    HIP_TRY(hipEventCreateWithFlags(&w.ev_done, hipEventDisableTiming));
+    return VRT_OK;
+}
+
+void workspace_free(Workspace &w)
+{
+    if (w.stream) { (void)hipStreamSynchronize(w.stream); (void)hipStreamDestroy(w.stream); }
+    for (hipEvent_t ev : {w.ev_begin, w.ev_end, w.ev_done}) if (ev) (void)hipEventDestroy(ev);
+    for (DevBuf *b : w.all) b->release();
+    w.err.release();
+    if (w.pin_err) (void)hipHostFree(w.pin_err);
+    w = Workspace();
+}
+
 int engine_init_device(vrt_engine *e)
 {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, e->device));
     e->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreate(&e->ev_begin));
-    HIP_TRY(hipEventCreate(&e->ev_end));
+    for (Workspace &w : e->ws) { const int rc = workspace_init(w); if (rc) return rc; }
     // +64 bytes of zeroed tail so that a 16-byte pair load at the very last voxel stays inside
     // the allocation (the march never reads it: the loop requires pos>>16 < bounds-1).
     HIP_TRY(hipMalloc(&e->field, e->field_bytes + 64));
-    HIP_TRY(hipMemsetAsync((char *)e->field + e->field_bytes, 0, 64, e->stream));
+    HIP_TRY(hipMemsetAsync((char *)e->field + e->field_bytes, 0, 64, e->ws[0].stream));
     return VRT_OK;
 }
 
 void engine_free(vrt_engine *e)
 {
     if (!e) return;
+    for (vrt_engine *r : e->replicas) engine_free(r);
+    e->replicas.clear();
     DeviceGuard g(e->device);
-    if (e->stream) { (void)hipStreamSynchronize(e->stream); (void)hipStreamDestroy(e->stream); }
+    for (Workspace &w : e->ws) workspace_free(w);
     if (e->field) (void)hipFree(e->field);
-    if (e->ev_begin) (void)hipEventDestroy(e->ev_begin);
-    if (e->ev_end) (void)hipEventDestroy(e->ev_end);
-    DevBuf *bufs[] = {&e->transl, &e->stats, &e->group_ctr, &e->sort_keys, &e->sort_keys_alt, &e->sort_vals, &e->sort_vals_alt, &e->sort_tmp, &e->sort_bounds,
-                      &e->h_in_pos, &e->h_in_dir, &e->h_out_pos, &e->h_out_dir, &e->h_out_iter, &e->h_out_light,
-                      &e->h_path};
-    for (DevBuf *b : bufs) b->release();
+    e->transl.release();
     delete e;
 }
 
@@ -224,8 +328,8 @@ int launch_typed(vrt_engine *e, const vrt::MarchParams &p, int kernel, hipStream
 {
     const bool path = p.path != nullptr;
     if (kernel == VRT_KERNEL_SLAB) {
-        return vrt::launch_slab<FieldT, DirT>(p, path, e->num_cu, s) == hipSuccess
-                   ? VRT_OK : fail(VRT_ERR_HIP, "slab kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+        const hipError_t le = vrt::launch_slab<FieldT, DirT>(p, path, e->num_cu, s);   // (hipGetLastError() clears the error it returns)
+        return le == hipSuccess ? VRT_OK : fail(VRT_ERR_HIP, "slab kernel launch failed: %s", hipGetErrorString(le));
     }
     const unsigned grid = (p.nrays + 255) / 256;
     if (p.transl) {
@@ -264,18 +368,29 @@ void step_window(const float *inv, uint32_t *lo, uint32_t *span)
     *span = base_hi - l;
 }
 
-int trace_device_impl(vrt_engine *e, int dir_type, size_t nrays, const uint32_t *d_sp, const void *d_sd,
+// Enqueue ray ordering + march for device-resident rays on stream `s`, using workspace `w` of engine `e`.
+// The workspace (ray order, group counter, debug counters) is shared by every call on the lane: a call on another
+// stream than the previous one first waits for that call's last kernel (ev_done), so two calls in flight on two
+// streams of one engine are ordered instead of overwriting each other's permutation.
+int trace_device_impl(vrt_engine *e, Workspace &w, int dir_type, size_t nrays, const uint32_t *d_sp, const void *d_sd,
                       uint32_t *d_ep, void *d_ed, uint32_t *d_ei, uint32_t *d_rl, uint32_t *d_path,
                       const float *invscale, uint32_t iterations, hipStream_t s, const vrt_options *opt,
                       uint32_t out_pos_bias = 0, uint32_t min_brightness = 0)
 {
     if (nrays == 0) return VRT_OK;
     const vrt_options &o = opt ? *opt : e->opt;
+    if (w.used) HIP_TRY(hipStreamWaitEvent(s, w.ev_done, 0));
     vrt::MarchParams p;
     p.field = e->field;
     p.Bx = e->B[0]; p.By = e->B[1]; p.Bz = e->B[2];
     p.invx = invscale[0]; p.invy = invscale[1]; p.invz = invscale[2];
     step_window(invscale, &p.win_lo, &p.win_span);
+    for (int d = 0; d < 3; ++d) {                        // upper bound of |g_d * inv_d| per step, rounded up (safe_steps)
+        const double g = (double)e->gmax[d] * std::fabs((double)invscale[d]) * (1.0 + 1.0 / 1048576.0);
+        float gf = (float)g;
+        if ((double)gf < g) gf = std::nextafterf(gf, INFINITY);
+        p.gstep[d] = gf;                                 // NaN / inf stay what they are: no round is proven then
+    }
     p.start_pos = d_sp; p.start_dir = d_sd;
     p.end_pos = d_ep; p.end_dir = d_ed; p.end_iter = d_ei; p.remaining_light = d_rl;
     p.path = d_path;
@@ -302,10 +417,10 @@ int trace_device_impl(vrt_engine *e, int dir_type, size_t nrays, const uint32_t 
     p.stats = nullptr;
     if (const char *dbg = getenv("VRT_DEBUG_STATS"); dbg && dbg[0] == '1') {
         // 64 counters, then (development builds with -DVRT_SLAB_TIMELINE) 4 words per wavefront
-        e->stats_count = 64 + 4 * (((size_t)nrays + 63) / 64);
-        HIP_TRY(e->stats.reserve(e->stats_count * sizeof(unsigned long long)));
-        HIP_TRY(hipMemsetAsync(e->stats.p, 0, e->stats_count * sizeof(unsigned long long), s));
-        p.stats = (unsigned long long *)e->stats.p;
+        w.stats_count = 64 + 4 * (((size_t)nrays + 63) / 64);
+        HIP_TRY(w.stats.reserve(w.stats_count * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(w.stats.p, 0, w.stats_count * sizeof(unsigned long long), s));
+        p.stats = (unsigned long long *)w.stats.p;
     }
     int kernel = o.kernel;
     if (kernel == VRT_KERNEL_AUTO) kernel = d_path ? VRT_KERNEL_DIRECT : VRT_KERNEL_SLAB;
@@ -316,12 +431,13 @@ int trace_device_impl(vrt_engine *e, int dir_type, size_t nrays, const uint32_t 
     // tile ordering: group rays that enter the field close together into the same wavefront
     const bool sort = o.sort_rays > 0 || (o.sort_rays == 0 && nrays >= 4096);
     if (sort) {
+        Range range("vrt: ray order");
         const uint32_t *order = nullptr, *wave_order = nullptr;
         // longest wavefronts first: always for 3; in auto mode only when the launch has more wavefronts than the
         // GPU holds at once (24 per CU at the default LDS segment) -- otherwise every wavefront starts at t = 0 anyway
         const int wave_lpt = !d_path && (o.sort_rays == 3 || (o.sort_rays == 0 && (nrays + 63) / 64 > (size_t)e->num_cu * 24));
-        hipError_t se = vrt::build_tile_order(d_sp, d_sd, dir_type, (uint32_t)nrays, e->B[0], e->B[1], e->B[2], o.sort_rays == 2 ? 1 : 0, e->sort_keys, e->sort_keys_alt,
-                                              e->sort_vals, e->sort_vals_alt, e->sort_tmp, e->sort_bounds, s, &order,
+        hipError_t se = vrt::build_tile_order(d_sp, d_sd, dir_type, (uint32_t)nrays, e->B[0], e->B[1], e->B[2], o.sort_rays == 2 ? 1 : 0, w.sort_keys, w.sort_keys_alt,
+                                              w.sort_vals, w.sort_vals_alt, w.sort_tmp, w.sort_bounds, s, &order,
                                               wave_lpt, iterations, &wave_order, e->field, e->field_type == VRT_I16, invscale);
         if (se != hipSuccess) return fail(se == hipErrorOutOfMemory ? VRT_ERR_OUT_OF_MEMORY : VRT_ERR_HIP,
                                           "ray tile ordering failed: %s", hipGetErrorString(se));
@@ -340,21 +456,30 @@ int trace_device_impl(vrt_engine *e, int dir_type, size_t nrays, const uint32_t 
         // auto: persistent once the launch has more wavefronts than the GPU holds (measured -4 % on config 3)
         if (schedule == 0) schedule = groups > (size_t)e->num_cu * 24 ? 2 : 1;
         if (schedule == 2 && kernel == VRT_KERNEL_SLAB && groups > 1) {
-            HIP_TRY(e->group_ctr.reserve(sizeof(uint32_t)));
-            HIP_TRY(hipMemsetAsync(e->group_ctr.p, 0, sizeof(uint32_t), s));
-            p.group_counter = (uint32_t *)e->group_ctr.p;
+            HIP_TRY(w.group_ctr.reserve(sizeof(uint32_t)));
+            HIP_TRY(hipMemsetAsync(w.group_ctr.p, 0, sizeof(uint32_t), s));
+            p.group_counter = (uint32_t *)w.group_ctr.p;
         }
     }
 
-    HIP_TRY(hipEventRecord(e->ev_begin, s));
+    // one wavefront of the march stamps (s_memtime, s_memrealtime) when it starts and when it ends: the clock the
+    // kernel really ran at, for the roofline's peak (vrt_engine_last_march_clock_ghz)
+    HIP_TRY(w.clock.reserve(4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(w.clock.p, 0, 4 * sizeof(unsigned long long), s));
+    p.clock_out = (unsigned long long *)w.clock.p;
+
+    Range range("vrt: march");
+    HIP_TRY(hipEventRecord(w.ev_begin, s));
     int rc;
     if (e->field_type == VRT_F32)
         rc = dir_type == VRT_F32 ? launch_typed<float, float>(e, p, kernel, s) : launch_typed<float, int16_t>(e, p, kernel, s);
     else
         rc = dir_type == VRT_F32 ? launch_typed<int16_t, float>(e, p, kernel, s) : launch_typed<int16_t, int16_t>(e, p, kernel, s);
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(e->ev_end, s));
-    e->ev_valid = true;
+    HIP_TRY(hipEventRecord(w.ev_end, s));
+    HIP_TRY(hipEventRecord(w.ev_done, s));
+    w.ev_valid = true;
+    w.used = true;
     return VRT_OK;
 }
 
@@ -374,63 +499,157 @@ int check_trace_args(vrt_handle h, int dir_type, size_t nrays, const void *sp, c
     return VRT_OK;
 }
 
-// Host-pointer trace shared by vrt_trace and vrt_scene_trace.  `pre` (optional) rewrites the
-// uploaded start arrays on the device before the march (the scene layer's ray prologue).
-template <typename Pre>
-int trace_host_impl(vrt_engine *e, int dir_type, size_t nrays, const uint32_t *sp, const void *sd, uint32_t *ep,
-                    void *ed, uint32_t *ei, uint32_t *rl, uint32_t *path, const float *invscale, uint32_t iterations,
-                    const vrt_options *opt, uint32_t out_pos_bias, uint32_t min_brightness, Pre pre)
-{
-    const vrt_options &o = opt ? *opt : e->opt;
-    const size_t dsz = dir_type == VRT_F32 ? 4 : 2;
-    hipStream_t s = e->stream;
-    // Rays go up in one piece when no path is requested; with path tracing the device path
-    // buffer (iterations*12 bytes per ray) bounds the chunk, as the reference's 0x8000-ray
-    // chunks bound its own (.cu:798, 840).
-    size_t chunk = nrays;
-    if (path) {
-        const size_t per_ray = (size_t)iterations * 12;
-        size_t budget = (size_t)2 << 30;
-        if (const char *b = getenv("VRT_PATH_BUDGET_BYTES")) {          // tests shrink it to force several chunks
-            const unsigned long long v = strtoull(b, nullptr, 10);
-            if (v > 0) budget = (size_t)v;
-        }
-        chunk = std::max<size_t>(1, std::min(nrays, budget / std::max<size_t>(per_ray, 1)));
-    }
-    HIP_TRY(e->h_in_pos.reserve(chunk * 12));
-    HIP_TRY(e->h_in_dir.reserve(chunk * 3 * dsz));
-    HIP_TRY(e->h_out_pos.reserve(chunk * 12));
-    HIP_TRY(e->h_out_dir.reserve(chunk * 3 * dsz));
-    HIP_TRY(e->h_out_iter.reserve(chunk * 4));
-    HIP_TRY(e->h_out_light.reserve(chunk * 4));
-    if (path) HIP_TRY(e->h_path.reserve(chunk * (size_t)iterations * 12));
+// ---- host-pointer calls ---------------------------------------------------------------------------------------
+// The reference copies each 0x8000-ray chunk up, runs it, waits and copies it back, one blocking step after the other
+// (cuda_volume_raytracer.cu:843, 905-910).  Here a call is cut into a few large chunks that are pipelined over the
+// engine's lanes (each lane: own stream, own staging buffers, own host thread): while lane A marches chunk k, lane B
+// uploads chunk k+1 and lane C downloads chunk k-1, so PCIe time hides behind the march.  With several devices
+// (vrt_options.devices) the rays are first cut into one contiguous band per device.  Results land directly in the
+// caller's arrays at the rays' own indices, so the output is independent of the cut.
+struct HostCall {
+    int dir_type;
+    const uint32_t *sp; const void *sd;
+    uint32_t *ep; void *ed; uint32_t *ei; uint32_t *rl; uint32_t *path;
+    const float *invscale;
+    uint32_t iterations, min_brightness, out_pos_bias;
+    const vrt_options *opt;
+};
 
-    const size_t nchunks = (nrays + chunk - 1) / chunk;
-    bool cap_hit = false;
-    for (size_t c = 0, off = 0; off < nrays; ++c, off += chunk) {
-        const size_t n = std::min(chunk, nrays - off);
-        if (o.loglevel < 0) printf("iteration %zu of %zu\n", c, nchunks);          // .cu:823-826
-        HIP_TRY(hipMemcpyAsync(e->h_in_pos.p, sp + 3 * off, n * 12, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(e->h_in_dir.p, (const char *)sd + 3 * off * dsz, n * 3 * dsz, hipMemcpyHostToDevice, s));
-        int rc = pre((uint32_t *)e->h_in_pos.p, e->h_in_dir.p, n, off, s);
-        if (rc) return rc;
-        rc = trace_device_impl(e, dir_type, n, (const uint32_t *)e->h_in_pos.p, e->h_in_dir.p,
-                               (uint32_t *)e->h_out_pos.p, e->h_out_dir.p, (uint32_t *)e->h_out_iter.p,
-                               (uint32_t *)e->h_out_light.p, path ? (uint32_t *)e->h_path.p : nullptr, invscale,
-                               iterations, s, opt, out_pos_bias, min_brightness);
-        if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(ep + 3 * off, e->h_out_pos.p, n * 12, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync((char *)ed + 3 * off * dsz, e->h_out_dir.p, n * 3 * dsz, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(ei + off, e->h_out_iter.p, n * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(rl + off, e->h_out_light.p, n * 4, hipMemcpyDeviceToHost, s));
-        if (path)
-            HIP_TRY(hipMemcpyAsync(path + off * (size_t)iterations * 3, e->h_path.p, n * (size_t)iterations * 12,
+// `pre` (optional) rewrites the uploaded start arrays on the device before the march (the scene layer's ray
+// prologue) and `post` inspects what it left behind once the chunk's stream has drained.
+struct ChunkHooks {
+    virtual int pre(vrt_engine *, Workspace &, uint32_t *, void *, size_t, size_t, hipStream_t) { return VRT_OK; }
+    virtual int post(vrt_engine *, Workspace &, size_t, size_t) { return VRT_OK; }
+    virtual ~ChunkHooks() {}
+};
+
+int trace_host_chunk(vrt_engine *e, Workspace &w, const HostCall &c, size_t off, size_t n, ChunkHooks &hooks)
+{
+    const size_t dsz = c.dir_type == VRT_F32 ? 4 : 2;
+    hipStream_t s = w.stream;
+    HIP_TRY(w.in_pos.reserve(n * 12));
+    HIP_TRY(w.in_dir.reserve(n * 3 * dsz));
+    HIP_TRY(w.out_pos.reserve(n * 12));
+    HIP_TRY(w.out_dir.reserve(n * 3 * dsz));
+    HIP_TRY(w.out_iter.reserve(n * 4));
+    HIP_TRY(w.out_light.reserve(n * 4));
+    if (c.path) HIP_TRY(w.path.reserve(n * (size_t)c.iterations * 12));
+    {
+        Range range("vrt: upload rays");
+        HIP_TRY(hipMemcpyAsync(w.in_pos.p, c.sp + 3 * off, n * 12, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(w.in_dir.p, (const char *)c.sd + 3 * off * dsz, n * 3 * dsz, hipMemcpyHostToDevice, s));
+    }
+    int rc = hooks.pre(e, w, (uint32_t *)w.in_pos.p, w.in_dir.p, n, off, s);
+    if (rc) return rc;
+    rc = trace_device_impl(e, w, c.dir_type, n, (const uint32_t *)w.in_pos.p, w.in_dir.p, (uint32_t *)w.out_pos.p,
+                           w.out_dir.p, (uint32_t *)w.out_iter.p, (uint32_t *)w.out_light.p,
+                           c.path ? (uint32_t *)w.path.p : nullptr, c.invscale, c.iterations, s, c.opt, c.out_pos_bias,
+                           c.min_brightness);
+    if (rc) return rc;
+    {
+        Range range("vrt: download results");
+        HIP_TRY(hipMemcpyAsync(c.ep + 3 * off, w.out_pos.p, n * 12, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync((char *)c.ed + 3 * off * dsz, w.out_dir.p, n * 3 * dsz, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(c.ei + off, w.out_iter.p, n * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(c.rl + off, w.out_light.p, n * 4, hipMemcpyDeviceToHost, s));
+        if (c.path)
+            HIP_TRY(hipMemcpyAsync(c.path + off * (size_t)c.iterations * 3, w.path.p, n * (size_t)c.iterations * 12,
                                    hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
     }
-    for (size_t i = 0; i < nrays && !cap_hit; ++i) cap_hit = (ei[i] == iterations);
+    return hooks.post(e, w, n, off);
+}
+
+// Contiguous cut of `n` rays into `parts` ranges whose sizes are multiples of 64 where possible (whole wavefronts),
+// first ranges taking the remainder.  Exported for tests through vrt_debug_band_cut.
+void band_cut(size_t n, size_t parts, std::vector<size_t> &begin)
+{
+    begin.assign(parts + 1, n);
+    const size_t groups = (n + 63) / 64;
+    size_t g0 = 0;
+    for (size_t k = 0; k < parts; ++k) {
+        begin[k] = std::min(n, g0 * 64);
+        g0 += groups / parts + (k < groups % parts ? 1 : 0);
+    }
+    begin[parts] = n;
+}
+
+// chunks per device for the lane pipeline: enough to hide the copies, few enough to keep every launch large
+size_t host_chunks(const vrt_options &o, size_t nrays, bool path)
+{
+    if (path) return 1;                                  // path tracing is chunked by the device path budget instead
+    int want = o.host_lanes;
+    if (const char *ev = getenv("VRT_HOST_LANES"); ev && want == 0) want = atoi(ev);
+    if (want <= 0) want = nrays >= ((size_t)1 << 19) ? 4 : (nrays >= ((size_t)1 << 17) ? 2 : 1);
+    return (size_t)std::min(want, 64);
+}
+
+int trace_host_impl(vrt_engine *e0, const HostCall &c, size_t nrays, ChunkHooks &hooks)
+{
+    const vrt_options &o = c.opt ? *c.opt : e0->opt;
+    // one band per device ...
+    std::vector<vrt_engine *> engs{e0};
+    for (vrt_engine *r : e0->replicas) engs.push_back(r);
+    if (nrays < 64 * engs.size() || nrays <= o.minimum_gpu) engs.resize(1);   // too few rays to be worth spreading
+    std::vector<size_t> band;
+    band_cut(nrays, engs.size(), band);
+
+    struct Task { vrt_engine *e; int lane; size_t off, n; };
+    std::vector<std::vector<Task>> per_thread;             // one host thread per (device, lane)
+    size_t nchunks_total = 0;
+    for (size_t d = 0; d < engs.size(); ++d) {
+        const size_t b0 = band[d], bn = band[d + 1] - band[d];
+        if (bn == 0) continue;
+        std::vector<size_t> cut;
+        if (c.path) {
+            // the device path buffer (iterations*12 bytes per ray) bounds the chunk, as the reference's 0x8000-ray
+            // chunks bound its own (.cu:798, 840)
+            const size_t per_ray = (size_t)c.iterations * 12;
+            size_t budget = (size_t)2 << 30;
+            if (const char *b = getenv("VRT_PATH_BUDGET_BYTES")) {          // tests shrink it to force several chunks
+                const unsigned long long v = strtoull(b, nullptr, 10);
+                if (v > 0) budget = (size_t)v;
+            }
+            const size_t chunk = std::max<size_t>(1, std::min(bn, budget / std::max<size_t>(per_ray, 1)));
+            for (size_t x = 0; x < bn; x += chunk) cut.push_back(x);
+            cut.push_back(bn);
+        } else {
+            band_cut(bn, host_chunks(o, bn, false), cut);
+        }
+        const size_t nch = cut.size() - 1;
+        const int lanes = c.path ? 1 : (int)std::min<size_t>(kLanes, nch);
+        const size_t first = per_thread.size();
+        per_thread.resize(first + lanes);
+        for (size_t k = 0; k < nch; ++k)
+            if (cut[k + 1] > cut[k]) {
+                per_thread[first + k % lanes].push_back(Task{engs[d], (int)(k % lanes), b0 + cut[k], cut[k + 1] - cut[k]});
+                ++nchunks_total;
+            }
+    }
+
+    std::vector<int> rcs(per_thread.size(), VRT_OK);
+    std::vector<std::string> errs(per_thread.size());
+    std::atomic<size_t> progress{0};
+    auto run = [&](size_t t) {
+        for (const Task &k : per_thread[t]) {
+            DeviceGuard g(k.e->device);
+            if (o.loglevel < 0) printf("iteration %zu of %zu\n", progress.fetch_add(1), nchunks_total);     // .cu:823-826
+            const int rc = trace_host_chunk(k.e, k.e->ws[k.lane], c, k.off, k.n, hooks);
+            if (rc) { rcs[t] = rc; errs[t] = g_err; return; }
+        }
+    };
+    if (per_thread.size() == 1) run(0);
+    else {
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < per_thread.size(); ++t) th.emplace_back(run, t);
+        for (auto &x : th) x.join();
+    }
+    for (size_t t = 0; t < rcs.size(); ++t)
+        if (rcs[t]) { g_err = errs[t]; return rcs[t]; }                 // the worker's thread-local message, on this thread
+    bool cap_hit = false;
+    for (size_t i = 0; i < nrays && !cap_hit; ++i) cap_hit = (c.ei[i] == c.iterations);
     if (cap_hit) printf("Warning, maximum iterations hitted\n");                   // .cu:512-515
-    if (o.loglevel < 0) printf("cpu: 0 gpu: %zu\n", nchunks);                      // .cu:948-951
+    if (o.loglevel < 0) printf("cpu: 0 gpu: %zu\n", nchunks_total);               // .cu:948-951
     return VRT_OK;
 }
 
@@ -459,8 +678,7 @@ struct vrt_scene {
     void *d_ior = nullptr;          // the ior volume stays resident for the ray prologue's interpolation
     void *d_density = nullptr;      // LUT scenes: the 8-bit volume stays resident instead, with its ior table
     void *d_lut_ior = nullptr;
-    void *d_err = nullptr;          // vrt::SceneErr
-    DevBuf pro_pos, pro_dir;
+    bool device_call_pending = false;   // a vrt_scene_trace_device call whose error words have not been looked at yet
 };
 
 // =============================================================================================
@@ -485,6 +703,62 @@ __global__ __launch_bounds__(256) void k_selftest_ilen2(unsigned long long *out 
     if ((threadIdx.x & 63u) == 0) { atomicAdd(&out[0], bad); atomicAdd(&out[1], adm); }
 }
 
+// Devices a new handle spans: vrt_options.devices is a bit mask of HIP ordinals (0 = just vrt_options.device, -1 = every
+// visible device).  The first device of the list owns the handle's primary engine.  VRT_DEBUG_REPLICAS=n (tests on a
+// one-GPU box) makes n engines on the primary device instead, so that the band cut and the merge run without peers.
+std::vector<int> handle_devices(const vrt_options &o, int primary, int ndev)
+{
+    std::vector<int> devs;
+    if (const char *ev = getenv("VRT_DEBUG_REPLICAS"); ev && atoi(ev) > 1 && o.devices == 0) {
+        devs.assign((size_t)std::min(atoi(ev), 16), primary);
+        return devs;
+    }
+    devs.push_back(primary);
+    if (o.devices != 0)
+        for (int d = 0; d < ndev && d < 32; ++d)
+            if (d != primary && ((uint32_t)o.devices >> d & 1u)) devs.push_back(d);
+    return devs;
+}
+
+// Replicate a finished engine's field (and translucency) onto the other devices of the handle, as the reference's
+// constructor does with cudaMemcpy from the host copy (cuda_volume_raytracer.cu:676-686) -- here device to device.
+int engine_replicate(vrt_engine *e)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 1;
+    const std::vector<int> devs = handle_devices(e->opt, e->device, ndev);
+    const uint16_t b16[3] = {(uint16_t)e->B[0], (uint16_t)e->B[1], (uint16_t)e->B[2]};
+    for (size_t k = 1; k < devs.size(); ++k) {
+        vrt_engine *r = nullptr;
+        vrt_options ro = e->opt;
+        ro.device = devs[k];
+        ro.devices = 0;
+        int rc = engine_alloc(&r, b16, e->field_type, e->nvox, &ro);
+        if (rc) return rc;
+        e->replicas.push_back(r);                       // owned by e from here on (engine_free walks the list)
+        DeviceGuard g(r->device);
+        rc = engine_init_device(r);
+        if (rc) return rc;
+        memcpy(r->gmax, e->gmax, sizeof r->gmax);
+        hipStream_t s = r->ws[0].stream;
+        if (r->device != e->device) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, r->device, e->device) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(e->device, 0);
+            (void)hipGetLastError();                     // "already enabled" is fine
+            HIP_TRY(hipMemcpyPeerAsync(r->field, r->device, e->field, e->device, e->field_bytes, s));
+        } else {
+            HIP_TRY(hipMemcpyAsync(r->field, e->field, e->field_bytes, hipMemcpyDeviceToDevice, s));
+        }
+        if (e->transl.p) {
+            HIP_TRY(r->transl.reserve(e->nvox * 4));
+            if (r->device != e->device) HIP_TRY(hipMemcpyPeerAsync(r->transl.p, r->device, e->transl.p, e->device, e->nvox * 4, s));
+            else HIP_TRY(hipMemcpyAsync(r->transl.p, e->transl.p, e->nvox * 4, hipMemcpyDeviceToDevice, s));
+        }
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return VRT_OK;
+}
+
 extern "C" {
 
 void vrt_options_default(vrt_options *opt)
@@ -498,6 +772,8 @@ void vrt_options_default(vrt_options *opt)
     opt->device = -1;
     opt->kernel = VRT_KERNEL_AUTO;
     opt->sort_rays = 0;
+    opt->devices = 0;
+    opt->host_lanes = 0;
 }
 
 int vrt_abi_version(void) { return VRT_ABI_VERSION; }
@@ -523,11 +799,13 @@ int vrt_create_from_device(vrt_handle *out, int dim, const uint16_t *bounds, int
     rc = engine_init_device(e);
     if (!rc && e->opt.absorption) {
         if (e->transl.reserve(nvox * 4) != hipSuccess) rc = fail(VRT_ERR_OUT_OF_MEMORY, "device allocation failed");
-        else if (hipMemcpyAsync(e->transl.p, d_tr, nvox * 4, hipMemcpyDeviceToDevice, e->stream) != hipSuccess)
+        else if (hipMemcpyAsync(e->transl.p, d_tr, nvox * 4, hipMemcpyDeviceToDevice, e->ws[0].stream) != hipSuccess)
             rc = fail(VRT_ERR_HIP, "translucency copy failed");
     }
-    if (!rc) rc = launch_interleave(e, d_diff, d_tr, 0, nvox, e->stream);
-    if (!rc && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail(VRT_ERR_HIP, "field interleave failed");
+    if (!rc) rc = launch_interleave(e, d_diff, d_tr, 0, nvox, e->ws[0].stream);
+    if (!rc && hipStreamSynchronize(e->ws[0].stream) != hipSuccess) rc = fail(VRT_ERR_HIP, "field interleave failed");
+    if (!rc) rc = engine_field_absmax(e, e->ws[0].stream);
+    if (!rc) rc = engine_replicate(e);
     if (rc) { engine_free(e); return rc; }
     *out = e;
     return VRT_OK;
@@ -560,19 +838,22 @@ int vrt_create(vrt_handle *out, int dim, const uint16_t *bounds, int field_type,
     for (size_t off = 0; off < nvox; off += chunk) {
         const size_t n = std::min(chunk, nvox - off);
         if (e->opt.absorption &&
-            hipMemcpyAsync((uint32_t *)e->transl.p + off, tr + off, n * 4, hipMemcpyHostToDevice, e->stream) != hipSuccess)
+            hipMemcpyAsync((uint32_t *)e->transl.p + off, tr + off, n * 4, hipMemcpyHostToDevice, e->ws[0].stream) != hipSuccess)
             return cleanup(fail(VRT_ERR_HIP, "field upload failed"));
         for (int k = 0; k < 3; ++k)
-            if (hipMemcpyAsync(tmp[k].p, (const char *)diff[k] + off * esz, n * esz, hipMemcpyHostToDevice, e->stream) != hipSuccess)
+            if (hipMemcpyAsync(tmp[k].p, (const char *)diff[k] + off * esz, n * esz, hipMemcpyHostToDevice, e->ws[0].stream) != hipSuccess)
                 return cleanup(fail(VRT_ERR_HIP, "field upload failed"));
-        if (hipMemcpyAsync(tmp[3].p, tr + off, n * 4, hipMemcpyHostToDevice, e->stream) != hipSuccess)
+        if (hipMemcpyAsync(tmp[3].p, tr + off, n * 4, hipMemcpyHostToDevice, e->ws[0].stream) != hipSuccess)
             return cleanup(fail(VRT_ERR_HIP, "field upload failed"));
         const void *d[3] = {tmp[0].p, tmp[1].p, tmp[2].p};
-        rc = launch_interleave(e, d, (const uint32_t *)tmp[3].p, off, n, e->stream);
+        rc = launch_interleave(e, d, (const uint32_t *)tmp[3].p, off, n, e->ws[0].stream);
         if (rc) return cleanup(rc);
-        if (hipStreamSynchronize(e->stream) != hipSuccess) return cleanup(fail(VRT_ERR_HIP, "field interleave failed"));
+        if (hipStreamSynchronize(e->ws[0].stream) != hipSuccess) return cleanup(fail(VRT_ERR_HIP, "field interleave failed"));
     }
     for (DevBuf &b : tmp) b.release();
+    rc = engine_field_absmax(e, e->ws[0].stream);
+    if (!rc) rc = engine_replicate(e);
+    if (rc) { engine_free(e); return rc; }
     *out = e;
     return VRT_OK;
 }
@@ -585,8 +866,9 @@ int vrt_trace_device(vrt_handle h, int dir_type, size_t nrays, const uint32_t *d
     int rc = check_trace_args(h, dir_type, nrays, d_sp, d_sd, d_ep, d_ed, d_ei, d_rl, invscale, iterations);
     if (rc) return rc;
     DeviceGuard g(h->device);
+    std::lock_guard<std::mutex> lock(h->mu);
     // min_brightness is ignored unless the opt-in absorption mode is on, as in the reference (.cu:785)
-    return trace_device_impl(h, dir_type, nrays, d_sp, d_sd, d_ep, d_ed, d_ei, d_rl, d_path, invscale, iterations,
+    return trace_device_impl(h, h->ws[0], dir_type, nrays, d_sp, d_sd, d_ep, d_ed, d_ei, d_rl, d_path, invscale, iterations,
                              (hipStream_t)stream, opt, 0, min_brightness);
 }
 
@@ -598,8 +880,10 @@ int vrt_trace(vrt_handle h, int dir_type, size_t nrays, const uint32_t *sp, cons
     if (rc) return rc;
     if (nrays == 0) return VRT_OK;
     DeviceGuard g(h->device);
-    return trace_host_impl(h, dir_type, nrays, sp, sd, ep, ed, ei, rl, path, invscale, iterations, opt, 0, min_brightness,
-                           [](uint32_t *, void *, size_t, size_t, hipStream_t) { return (int)VRT_OK; });
+    std::lock_guard<std::mutex> lock(h->mu);
+    const HostCall c{dir_type, sp, sd, ep, ed, ei, rl, path, invscale, iterations, min_brightness, 0u, opt};
+    ChunkHooks none;
+    return trace_host_impl(h, c, nrays, none);
 }
 
 // ---- scene layer ---------------------------------------------------------------------------
@@ -665,19 +949,20 @@ static int scene_create_impl(vrt_scene_handle *out, int dim, const size_t *bound
     sc->engine = e;
     sc->ior_type = ior_type;
     for (int d = 0; d < 3; ++d) sc->N[d] = (uint32_t)bounds[d];
-    void *d_lg = nullptr, *d_tr = nullptr;
+    void *d_lg = nullptr, *d_tr = nullptr, *d_err = nullptr;
     auto cleanup = [&](int code) {
         if (d_lg) (void)hipFree(d_lg);
         if (d_tr) (void)hipFree(d_tr);
+        if (d_err) (void)hipFree(d_err);
         vrt_scene_destroy(sc);
         return code;
     };
     rc = engine_init_device(e);
     if (rc) return cleanup(rc);
-    hipStream_t s = e->stream;
+    hipStream_t s = e->ws[0].stream;
     const size_t ntab = density ? 256 : nvox;
     if (hipMalloc(&d_lg, ntab * 4) != hipSuccess || hipMalloc(&d_tr, ntab * 4) != hipSuccess ||
-        hipMalloc(&sc->d_err, sizeof(vrt::SceneErr)) != hipSuccess)
+        hipMalloc(&d_err, sizeof(vrt::SceneErr)) != hipSuccess)
         return cleanup(fail(VRT_ERR_OUT_OF_MEMORY, "device allocation failed"));
     if (density) {
         if (hipMalloc(&sc->d_density, nvox) != hipSuccess || hipMalloc(&sc->d_lut_ior, 256 * 4) != hipSuccess)
@@ -692,7 +977,7 @@ static int scene_create_impl(vrt_scene_handle *out, int dim, const size_t *bound
     }
     if (hipMemcpyAsync(d_lg, lg.data(), ntab * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
         hipMemcpyAsync(d_tr, translucency, ntab * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
-        hipMemsetAsync(sc->d_err, 0, sizeof(vrt::SceneErr), s) != hipSuccess)
+        hipMemsetAsync(d_err, 0, sizeof(vrt::SceneErr), s) != hipSuccess)
         return cleanup(fail(VRT_ERR_HIP, "scene upload failed"));
     uint32_t *d_tc = nullptr;
     if (e->opt.absorption) {
@@ -700,8 +985,9 @@ static int scene_create_impl(vrt_scene_handle *out, int dim, const size_t *bound
         d_tc = (uint32_t *)e->transl.p;
     }
     const unsigned grid = (unsigned)((fvox + 255) / 256);
-    vrt::SceneErr *derr = (vrt::SceneErr *)sc->d_err;
+    vrt::SceneErr *derr = (vrt::SceneErr *)d_err;
     const uint8_t *dd = (const uint8_t *)sc->d_density;
+    Range range("vrt: scene build");
     if (ior_type == VRT_F32) {
         if (density)
             vrt::k_scene_build<<<grid, 256, 0, s>>>(vrt::SrcLut<float>{dd, (const float *)d_lg}, vrt::SrcLut<uint32_t>{dd, (const uint32_t *)d_tr},
@@ -719,13 +1005,16 @@ static int scene_create_impl(vrt_scene_handle *out, int dim, const size_t *bound
     }
     if (hipGetLastError() != hipSuccess) return cleanup(fail(VRT_ERR_HIP, "scene build launch failed"));
     vrt::SceneErr herr;
-    if (hipMemcpyAsync(&herr, sc->d_err, sizeof herr, hipMemcpyDeviceToHost, s) != hipSuccess ||
+    if (hipMemcpyAsync(&herr, d_err, sizeof herr, hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess)
         return cleanup(fail(VRT_ERR_HIP, "scene build failed: %s", hipGetErrorString(hipGetLastError())));
     if (herr.diff_overflow) return cleanup(fail(VRT_ERR_SCENE, "differention overflow"));          // image_util.cpp:291-293
+    rc = engine_field_absmax(e, s);
+    if (rc) return cleanup(rc);
     (void)hipFree(d_lg);
     (void)hipFree(d_tr);
-    d_lg = d_tr = nullptr;
+    (void)hipFree(d_err);
+    d_lg = d_tr = d_err = nullptr;
     *out = sc;
     return VRT_OK;
 }
@@ -743,6 +1032,76 @@ int vrt_scene_create_lut(vrt_scene_handle *out, int dim, const size_t *bounds, i
     return scene_create_impl(out, dim, bounds, ior_type, density, lut_ior, lut_translucency, nvox, opt);
 }
 
+}  // extern "C"
+
+namespace {
+
+// The scene layer's ray front end (RaytraceScene::trace_rays, image_util.cpp:673-722) as chunk hooks: the prologue
+// kernel rewrites the start arrays in place on the chunk's stream, the march follows without any host round trip, and
+// the error words (range check, normalisation overflow) come back with the results and are looked at afterwards.
+int scene_prologue(vrt_scene *sc, Workspace &w, int dir_type, const uint32_t *d_pos_in, const void *d_dir_in,
+                   uint32_t *d_pos_out, void *d_dir_out, size_t n, hipStream_t s)
+{
+    HIP_TRY(w.err.reserve(sizeof(vrt::SceneErr)));
+    if (!w.pin_err) HIP_TRY(hipHostMalloc(&w.pin_err, sizeof(vrt::SceneErr), hipHostMallocDefault));
+    HIP_TRY(hipMemsetAsync(w.err.p, 0, sizeof(vrt::SceneErr), s));
+    HIP_TRY(hipMemsetAsync((char *)w.err.p + offsetof(vrt::SceneErr, first_bad_ray), 0xFF, 4, s));
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    vrt::SceneErr *derr = (vrt::SceneErr *)w.err.p;
+    const uint8_t *dd = (const uint8_t *)sc->d_density;
+    Range range("vrt: ray prologue");
+    if (dir_type == VRT_F32) {
+        if (dd) vrt::k_ray_prologue<<<grid, 256, 0, s>>>(vrt::SrcLut<float>{dd, (const float *)sc->d_lut_ior}, sc->N[0], sc->N[1], sc->N[2], d_pos_in,
+                                                         (const float *)d_dir_in, d_pos_out, (float *)d_dir_out, (uint32_t)n, derr);
+        else    vrt::k_ray_prologue<<<grid, 256, 0, s>>>(vrt::SrcArray<float>{(const float *)sc->d_ior}, sc->N[0], sc->N[1], sc->N[2], d_pos_in,
+                                                         (const float *)d_dir_in, d_pos_out, (float *)d_dir_out, (uint32_t)n, derr);
+    } else {
+        if (dd) vrt::k_ray_prologue<<<grid, 256, 0, s>>>(vrt::SrcLut<uint32_t>{dd, (const uint32_t *)sc->d_lut_ior}, sc->N[0], sc->N[1], sc->N[2], d_pos_in,
+                                                         (const int16_t *)d_dir_in, d_pos_out, (int16_t *)d_dir_out, (uint32_t)n, derr);
+        else    vrt::k_ray_prologue<<<grid, 256, 0, s>>>(vrt::SrcArray<uint32_t>{(const uint32_t *)sc->d_ior}, sc->N[0], sc->N[1], sc->N[2], d_pos_in,
+                                                         (const int16_t *)d_dir_in, d_pos_out, (int16_t *)d_dir_out, (uint32_t)n, derr);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(w.pin_err, w.err.p, sizeof(vrt::SceneErr), hipMemcpyDeviceToHost, s));   // pinned: truly asynchronous
+    return VRT_OK;
+}
+
+struct SceneHooks : ChunkHooks {
+    vrt_scene *sc;
+    int dir_type;
+    std::atomic<unsigned long long> first_bad{~0ull};
+    std::atomic<int> normalize_overflow{0};
+    SceneHooks(vrt_scene *s, int dt) : sc(s), dir_type(dt) {}
+    int pre(vrt_engine *, Workspace &w, uint32_t *d_pos, void *d_dir, size_t n, size_t, hipStream_t s) override
+    {
+        return scene_prologue(sc, w, dir_type, d_pos, d_dir, d_pos, d_dir, n, s);
+    }
+    int post(vrt_engine *, Workspace &w, size_t, size_t off) override
+    {
+        const vrt::SceneErr *h = (const vrt::SceneErr *)w.pin_err;
+        if (h->first_bad_ray != 0xFFFFFFFFu) {
+            unsigned long long i = off + h->first_bad_ray, cur = first_bad.load();
+            while (i < cur && !first_bad.compare_exchange_weak(cur, i)) {}
+            return VRT_ERR_RAY_RANGE;
+        }
+        if (h->normalize_overflow) { normalize_overflow.store(1); return VRT_ERR_SCENE; }
+        return VRT_OK;
+    }
+};
+
+int scene_check_trace_args(vrt_scene *sc, int dir_type)
+{
+    if ((sc->ior_type == VRT_F32) != (dir_type == VRT_F32))
+        return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_scene_trace: a %s scene takes %s directions (the reference instantiates "
+                    "only <float,float> and <ior_t,dir_t>, image_util.cpp:940-956)",
+                    sc->ior_type == VRT_F32 ? "float" : "fixed-point", sc->ior_type == VRT_F32 ? "float" : "int16");
+    return VRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int vrt_scene_trace(vrt_scene_handle sc, int dir_type, size_t nrays, const uint32_t *sp, const void *sd, uint32_t *ep,
                     void *ed, uint32_t *ei, uint32_t *rl, uint32_t *path, const float *invscale,
                     uint32_t min_brightness, uint32_t iterations, int /*normalize_length: "|| true", image_util.cpp:668*/,
@@ -752,48 +1111,66 @@ int vrt_scene_trace(vrt_scene_handle sc, int dir_type, size_t nrays, const uint3
     vrt_engine *e = sc->engine;
     int rc = check_trace_args(e, dir_type, nrays, sp, sd, ep, ed, ei, rl, invscale, iterations);
     if (rc) return rc;
-    if ((sc->ior_type == VRT_F32) != (dir_type == VRT_F32))
-        return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_scene_trace: a %s scene takes %s directions (the reference instantiates "
-                    "only <float,float> and <ior_t,dir_t>, image_util.cpp:940-956)",
-                    sc->ior_type == VRT_F32 ? "float" : "fixed-point", sc->ior_type == VRT_F32 ? "float" : "int16");
+    rc = scene_check_trace_args(sc, dir_type);
+    if (rc) return rc;
     if (nrays == 0) return VRT_OK;
     DeviceGuard g(e->device);
+    std::lock_guard<std::mutex> lock(e->mu);
+    const HostCall c{dir_type, sp, sd, ep, ed, ei, rl, path, invscale, iterations, min_brightness, 0x10000u, opt};
+    SceneHooks hooks(sc, dir_type);
+    rc = trace_host_impl(e, c, nrays, hooks);
+    if (hooks.first_bad.load() != ~0ull) {                                          // image_util.cpp:690-695
+        const size_t i = (size_t)hooks.first_bad.load();
+        return fail(VRT_ERR_RAY_RANGE, "ray %zu:%g %g %g is not in 0 to %u %u %u", i, sp[3 * i] / 65536.0,
+                    sp[3 * i + 1] / 65536.0, sp[3 * i + 2] / 65536.0, sc->N[0], sc->N[1], sc->N[2]);
+    }
+    if (hooks.normalize_overflow.load())                                            // image_util.cpp:705-708
+        return fail(VRT_ERR_SCENE, "Normalize length failed: -32768<=tmp<=32767");
+    return rc;
+}
+
+int vrt_scene_trace_device(vrt_scene_handle sc, int dir_type, size_t nrays, const uint32_t *d_sp, const void *d_sd,
+                           uint32_t *d_ep, void *d_ed, uint32_t *d_ei, uint32_t *d_rl, uint32_t *d_path,
+                           const float *invscale, uint32_t min_brightness, uint32_t iterations, void *stream,
+                           const vrt_options *opt)
+{
+    if (!sc) return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_scene_trace_device: NULL scene");
+    vrt_engine *e = sc->engine;
+    int rc = check_trace_args(e, dir_type, nrays, d_sp, d_sd, d_ep, d_ed, d_ei, d_rl, invscale, iterations);
+    if (rc) return rc;
+    rc = scene_check_trace_args(sc, dir_type);
+    if (rc) return rc;
+    if (nrays == 0) return VRT_OK;
+    DeviceGuard g(e->device);
+    std::lock_guard<std::mutex> lock(e->mu);
+    Workspace &w = e->ws[0];
+    hipStream_t s = (hipStream_t)stream;
     const size_t dsz = dir_type == VRT_F32 ? 4 : 2;
-    auto pre = [&](uint32_t *d_pos, void *d_dir, size_t n, size_t off, hipStream_t s) -> int {
-        HIP_TRY(sc->pro_pos.reserve(n * 12));
-        HIP_TRY(sc->pro_dir.reserve(n * 3 * dsz));
-        vrt::SceneErr init = {0u, 0xFFFFFFFFu, 0u};
-        HIP_TRY(hipMemcpyAsync(sc->d_err, &init, sizeof init, hipMemcpyHostToDevice, s));
-        const unsigned grid = (unsigned)((n + 255) / 256);
-        vrt::SceneErr *derr = (vrt::SceneErr *)sc->d_err;
-        const uint8_t *dd = (const uint8_t *)sc->d_density;
-        if (dir_type == VRT_F32) {
-            if (dd) vrt::k_ray_prologue<<<grid, 256, 0, s>>>(vrt::SrcLut<float>{dd, (const float *)sc->d_lut_ior}, sc->N[0], sc->N[1], sc->N[2], d_pos,
-                                                             (const float *)d_dir, (uint32_t *)sc->pro_pos.p, (float *)sc->pro_dir.p, (uint32_t)n, derr);
-            else    vrt::k_ray_prologue<<<grid, 256, 0, s>>>(vrt::SrcArray<float>{(const float *)sc->d_ior}, sc->N[0], sc->N[1], sc->N[2], d_pos,
-                                                             (const float *)d_dir, (uint32_t *)sc->pro_pos.p, (float *)sc->pro_dir.p, (uint32_t)n, derr);
-        } else {
-            if (dd) vrt::k_ray_prologue<<<grid, 256, 0, s>>>(vrt::SrcLut<uint32_t>{dd, (const uint32_t *)sc->d_lut_ior}, sc->N[0], sc->N[1], sc->N[2], d_pos,
-                                                             (const int16_t *)d_dir, (uint32_t *)sc->pro_pos.p, (int16_t *)sc->pro_dir.p, (uint32_t)n, derr);
-            else    vrt::k_ray_prologue<<<grid, 256, 0, s>>>(vrt::SrcArray<uint32_t>{(const uint32_t *)sc->d_ior}, sc->N[0], sc->N[1], sc->N[2], d_pos,
-                                                             (const int16_t *)d_dir, (uint32_t *)sc->pro_pos.p, (int16_t *)sc->pro_dir.p, (uint32_t)n, derr);
-        }
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(d_pos, sc->pro_pos.p, n * 12, hipMemcpyDeviceToDevice, s));
-        HIP_TRY(hipMemcpyAsync(d_dir, sc->pro_dir.p, n * 3 * dsz, hipMemcpyDeviceToDevice, s));
-        vrt::SceneErr herr;
-        HIP_TRY(hipMemcpyAsync(&herr, sc->d_err, sizeof herr, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        if (herr.first_bad_ray != 0xFFFFFFFFu) {                                   // image_util.cpp:690-695
-            const size_t i = off + herr.first_bad_ray;
-            return fail(VRT_ERR_RAY_RANGE, "ray %zu:%g %g %g is not in 0 to %u %u %u", i, sp[3 * i] / 65536.0,
-                        sp[3 * i + 1] / 65536.0, sp[3 * i + 2] / 65536.0, sc->N[0], sc->N[1], sc->N[2]);
-        }
-        if (herr.normalize_overflow)                                               // image_util.cpp:705-708
-            return fail(VRT_ERR_SCENE, "Normalize length failed: -32768<=tmp<=32767");
-        return VRT_OK;
-    };
-    return trace_host_impl(e, dir_type, nrays, sp, sd, ep, ed, ei, rl, path, invscale, iterations, opt, 0x10000u, min_brightness, pre);
+    if (w.used) HIP_TRY(hipStreamWaitEvent(s, w.ev_done, 0));      // the prologue buffers below belong to the lane too
+    HIP_TRY(w.pro_pos.reserve(nrays * 12));
+    HIP_TRY(w.pro_dir.reserve(nrays * 3 * dsz));
+    rc = scene_prologue(sc, w, dir_type, d_sp, d_sd, (uint32_t *)w.pro_pos.p, w.pro_dir.p, nrays, s);
+    if (rc) return rc;
+    sc->device_call_pending = true;
+    return trace_device_impl(e, w, dir_type, nrays, (const uint32_t *)w.pro_pos.p, w.pro_dir.p, d_ep, d_ed, d_ei, d_rl, d_path,
+                             invscale, iterations, s, opt, 0x10000u, min_brightness);
+}
+
+int vrt_scene_trace_status(vrt_scene_handle sc)
+{
+    if (!sc) return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_scene_trace_status: NULL scene");
+    if (!sc->device_call_pending) return VRT_OK;
+    vrt_engine *e = sc->engine;
+    DeviceGuard g(e->device);
+    std::lock_guard<std::mutex> lock(e->mu);
+    Workspace &w = e->ws[0];
+    HIP_TRY(hipEventSynchronize(w.ev_done));
+    sc->device_call_pending = false;
+    const vrt::SceneErr *h = (const vrt::SceneErr *)w.pin_err;
+    if (h->first_bad_ray != 0xFFFFFFFFu)
+        return fail(VRT_ERR_RAY_RANGE, "ray %u is not in 0 to %u %u %u", h->first_bad_ray, sc->N[0], sc->N[1], sc->N[2]);
+    if (h->normalize_overflow) return fail(VRT_ERR_SCENE, "Normalize length failed: -32768<=tmp<=32767");
+    return VRT_OK;
 }
 
 void vrt_scene_destroy(vrt_scene_handle sc)
@@ -804,9 +1181,6 @@ void vrt_scene_destroy(vrt_scene_handle sc)
         if (sc->d_ior) (void)hipFree(sc->d_ior);
         if (sc->d_density) (void)hipFree(sc->d_density);
         if (sc->d_lut_ior) (void)hipFree(sc->d_lut_ior);
-        if (sc->d_err) (void)hipFree(sc->d_err);
-        sc->pro_pos.release();
-        sc->pro_dir.release();
         engine_free(sc->engine);
     }
     delete sc;
@@ -820,24 +1194,47 @@ int vrt_engine_device(vrt_handle h) { return h ? h->device : -1; }
 size_t vrt_engine_field_bytes(vrt_handle h) { return h ? h->field_bytes : 0; }
 const void *vrt_engine_field_device_ptr(vrt_handle h) { return h ? h->field : nullptr; }
 
+int vrt_engine_replica_count(vrt_handle h) { return h ? 1 + (int)h->replicas.size() : 0; }
+
 int vrt_engine_debug_stats(vrt_handle h, unsigned long long *out, int n)
 {
     if (!h || !out || n <= 0) return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_engine_debug_stats: bad argument");
-    if (!h->stats.p) return fail(VRT_ERR_INVALID_ARGUMENT, "debug stats not enabled (set VRT_DEBUG_STATS=1)");
+    Workspace &w = h->ws[0];
+    if (!w.stats.p) return fail(VRT_ERR_INVALID_ARGUMENT, "debug stats not enabled (set VRT_DEBUG_STATS=1)");
     DeviceGuard g(h->device);
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, h->stats.p, sizeof(unsigned long long) * std::min((size_t)n, h->stats_count), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, w.stats.p, sizeof(unsigned long long) * std::min((size_t)n, w.stats_count), hipMemcpyDeviceToHost));
     return VRT_OK;
 }
 
 float vrt_engine_last_march_ms(vrt_handle h)
 {
-    if (!h || !h->ev_valid) return -1.0f;
+    if (!h || !h->ws[0].ev_valid) return -1.0f;
     DeviceGuard g(h->device);
     float ms = -1.0f;
-    if (hipEventSynchronize(h->ev_end) != hipSuccess) return -1.0f;
-    if (hipEventElapsedTime(&ms, h->ev_begin, h->ev_end) != hipSuccess) return -1.0f;
+    if (hipEventSynchronize(h->ws[0].ev_end) != hipSuccess) return -1.0f;
+    if (hipEventElapsedTime(&ms, h->ws[0].ev_begin, h->ws[0].ev_end) != hipSuccess) return -1.0f;
     return ms;
+}
+
+float vrt_engine_last_march_clock_ghz(vrt_handle h)
+{
+    if (!h || !h->ws[0].ev_valid || !h->ws[0].clock.p) return -1.0f;
+    DeviceGuard g(h->device);
+    unsigned long long c[4] = {0, 0, 0, 0};
+    if (hipEventSynchronize(h->ws[0].ev_end) != hipSuccess) return -1.0f;
+    if (hipMemcpy(c, h->ws[0].clock.p, sizeof c, hipMemcpyDeviceToHost) != hipSuccess) return -1.0f;
+    if (c[3] <= c[1] || c[2] <= c[0]) return -1.0f;                   // (s_memrealtime counts at 100 MHz)
+    return (float)((double)(c[2] - c[0]) / (double)(c[3] - c[1]) * 0.1);
+}
+
+int vrt_debug_band_cut(size_t n, size_t parts, size_t *begin /* parts + 1 */)
+{
+    if (!begin || parts == 0) return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_debug_band_cut: bad argument");
+    std::vector<size_t> b;
+    band_cut(n, parts, b);
+    for (size_t k = 0; k <= parts; ++k) begin[k] = b[k];
+    return VRT_OK;
 }
 
 int vrt_selftest_ilen2(int device, unsigned long long *mismatches, unsigned long long *admitted)

@@ -41,6 +41,9 @@ struct MarchParams {
     uint32_t *group_counter;  // persistent slab kernel only: next group of 64 slots to start (zeroed per launch)
     uint32_t out_pos_bias;    // added to end_pos / path on output: 0 at the seam, 0x10000 for the scene
                               // layer's "+0x10000" epilogue (image_util.cpp:770-771)
+    unsigned long long *clock_out; // optional: 4 words {s_memtime, s_memrealtime} x {begin, end} of one wavefront (wave 0 of block 0)
+    float gstep[3];           // slab kernel: upper bound of |g_d * inv_d|, the change of dir_d in one step (.cu:344-345):
+                              // max |field channel d| over the whole field x |inv_d|, rounded up (see safe_steps, vrt_slab.h)
 };
 
 struct f4 { float x, y, z, w; };
@@ -183,6 +186,51 @@ __device__ __forceinline__ bool march_step(Ray &r, const f4 (&c)[8], float invx,
     r.py += round_half_i32((r.dy * invy) * ilen2);
     r.pz += round_half_i32((r.dz * invz) * ilen2);
     return false;
+}
+
+// The same step for loops that carry no opacity test (check_w == false), written so that the common case has no
+// two-sided divergent region: every lane takes the short division and the integer rounding, and lanes whose |dir|^2
+// lies outside the fast-path window (none, normally: one untaken-in-effect scalar branch) are repaired the long way.
+// Results are identical to march_step(..., check_w = false) lane by lane.
+struct Weights { float wrx, wlx, wry, wly, wrz, wlz; };
+__device__ __forceinline__ Weights lerp_weights(const Ray &r)
+{
+    Weights w;
+    w.wrx = (float)(r.px & 0xFFFFu); w.wlx = 65536.0f - w.wrx;
+    w.wry = (float)(r.py & 0xFFFFu); w.wly = 65536.0f - w.wry;
+    w.wrz = (float)(r.pz & 0xFFFFu); w.wlz = 65536.0f - w.wrz;
+    return w;
+}
+__device__ __forceinline__ void march_step_now(Ray &r, const f4 (&c)[8], const Weights &w, float invx, float invy, float invz, StepWindow win)
+{
+    const float wrx = w.wrx, wlx = w.wlx, wry = w.wry, wly = w.wly, wrz = w.wrz, wlz = w.wlz;
+    float g[3];
+    {
+        float a00, a01, a10, a11, b0, b1;
+#define VRT_CH(ch, out)                                                                         \
+        a00 = lerp_(c[0].ch, wlx, c[4].ch, wrx); a01 = lerp_(c[1].ch, wlx, c[5].ch, wrx);        \
+        a10 = lerp_(c[2].ch, wlx, c[6].ch, wrx); a11 = lerp_(c[3].ch, wlx, c[7].ch, wrx);        \
+        b0 = lerp_(a00, wly, a10, wry); b1 = lerp_(a01, wly, a11, wry);                          \
+        out = lerp_(b0, wlz, b1, wrz) * (1.0f / 0x1000000000000p0f);
+        VRT_CH(x, g[0]) VRT_CH(y, g[1]) VRT_CH(z, g[2])
+#undef VRT_CH
+    }
+    r.dx = fma_(g[0], invx, r.dx);
+    r.dy = fma_(g[1], invy, r.dy);
+    r.dz = fma_(g[2], invz, r.dz);
+    const float dot = fma_(r.dz, r.dz, fma_(r.dx, r.dx, r.dy * r.dy));
+    const float ex = r.dx * invx, ey = r.dy * invy, ez = r.dz * invz;
+    const float ilen2 = ilen2_short(dot);                   // garbage outside the window, replaced below
+    uint32_t sx = round_half_i32(ex * ilen2), sy = round_half_i32(ey * ilen2), sz = round_half_i32(ez * ilen2);
+    const bool outside = !((__float_as_uint(dot) - win.lo) < win.span);
+    if (outside) {                                          // rare: skipped by one scalar branch when no lane needs it
+        const float ilen = 0x42000000p0f / dot;
+        const float il2 = ilen + ilen;
+        sx = (uint32_t)round_to_i32((ex * il2) * 0.5f);
+        sy = (uint32_t)round_to_i32((ey * il2) * 0.5f);
+        sz = (uint32_t)round_to_i32((ez * il2) * 0.5f);
+    }
+    r.px += sx; r.py += sy; r.pz += sz;
 }
 
 __device__ __forceinline__ bool in_field(const Ray &r, uint32_t bx1, uint32_t by1, uint32_t bz1)

@@ -162,8 +162,8 @@ __device__ __forceinline__ uint32_t interp_ior_u(const Src ior, uint32_t Ny, uin
 
 template <typename IorSrc, typename DirT>
 __global__ __launch_bounds__(256) void k_ray_prologue(const IorSrc ior, uint32_t Nx, uint32_t Ny, uint32_t Nz,
-                                                      const uint32_t *__restrict__ pos_in, const DirT *__restrict__ dir_in,
-                                                      uint32_t *__restrict__ pos_out, DirT *__restrict__ dir_out,
+                                                      const uint32_t *pos_in, const DirT *dir_in,
+                                                      uint32_t *pos_out, DirT *dir_out,   // may alias the inputs: each thread reads its ray first
                                                       uint32_t n, SceneErr *err)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -50,6 +50,10 @@ constexpr int kSlabMaxK = VRT_SLAB_MAXK;   // longest planned round, steps
 #define VRT_SLAB_DIRECT_STEPS 64
 #endif
 constexpr int kSlabDirectSteps = VRT_SLAB_DIRECT_STEPS;    // global-gather steps before re-planning for a wave that stages no brick
+#ifndef VRT_SLAB_MINSAFE
+#define VRT_SLAB_MINSAFE 6
+#endif
+constexpr int kSlabMinSafe = VRT_SLAB_MINSAFE;   // a proven run shorter than this is not worth a round: take the tested loop
 #ifndef VRT_SLAB_MINK
 #define VRT_SLAB_MINK 8
 #endif
@@ -87,7 +91,7 @@ __device__ __forceinline__ uint64_t lane_mask(bool b) { return __builtin_amdgcn_
 
 // debug counters (MarchParams::stats != nullptr): per-wave events, added by lane 0
 enum { kStatRounds = 0, kStatPlannedK, kStatLdsWaveSteps, kStatDirectRounds, kStatDirectWaveSteps, kStatVoxStaged,
-       kStatEarlyExit, kStatCount };
+       kStatEarlyExit, kStatProvenRounds, kStatCount, kStatProvenSteps = 13 };
 __device__ __forceinline__ void stat_add(const MarchParams &p, int which, unsigned long long v)
 {
 #ifdef VRT_SLAB_STATS      // development builds only (tools/build_debug.sh): keeps the branches out of the hot loop
@@ -158,6 +162,57 @@ __device__ __forceinline__ uint32_t plan_brick(const PlanIn &in, int K, const ui
     return big ? cap + 1 : vol;
 }
 
+// ---- guaranteed rounds ------------------------------------------------------------------------------------------
+// The planned K is a prediction (rays bend), so the general round tests every lane against the brick on every step
+// (three compares, a handful of scalar mask operations and branches: 13 % of a step, tools/ubench/step_rate.hip).
+// safe_steps() instead PROVES, per lane, a number of steps during which the ray cannot leave the staged brick; the
+// wavefront takes the minimum over its live lanes and runs that many steps with no test at all.
+//
+// Notation (internal units): D = dir, E_d = D_d * inv_d, dot = |D|^2, C = 0x42000000.  One step (.cu:344-347):
+//   D_d += g_d * inv_d,  |g_d * inv_d| <= G_d := gstep[d] (max |field_d| * |inv_d|: the interpolation is a convex
+//   combination; its three fma levels and the exact 2^-48 add a factor (1 + 2^-20) at most, and the fma of the update
+//   at most |D| * 2^-23 -- both covered by `slack` below);
+//   pos_d += s_d,  s_d = roundf(E_d * (C / dot)),  |s_d| <= |E_d| * C / dot * (1 + 2^-20) + 0.5, sign(s_d) = sign(E_d).
+// Over j <= K steps |D_d| grows by at most K G_d and |D| shrinks by at most R := K (Gx + Gy + Gz).  With rho := R / |D| <= 1/4:
+//   C / dot_j <= C / (dot (1 - rho)^2),
+// so every step moves the ray by at most  up_d = (max(E_d, 0) + K G_d |inv_d|) * C / (dot (1 - rho)^2) + 0.5  towards +d and by
+// at most dn_d (the same with max(-E_d, 0)) towards -d (rho is evaluated 2^-9 too large and the quotient 2^-9 too large again).  The ray gathers at positions p, p + s_1, ... before steps 0, 1, ...:
+// it is inside the brick (cell <= e_d - 2, relative position in [0, H_d)) before step j as long as
+// j * up_d <= H_d - 1 - p_d and j * dn_d <= p_d.  The divisions are evaluated with v_rcp_f32 and scaled down by
+// (1 - 2^-13), far more than the three roundings involved; a NaN or infinite direction fails `ok` and yields 1 (the
+// position the lane has now is inside the brick by construction).
+__device__ __forceinline__ uint32_t safe_steps(const Ray &r /* relative to the brick origin */, float invx, float invy, float invz,
+                                               float gx, float gy, float gz, int K, uint32_t hx, uint32_t hy, uint32_t hz /* H_d - 1 */)
+{
+    const float dot = fma_(r.dz, r.dz, fma_(r.dx, r.dx, r.dy * r.dy));
+    const float rc = __builtin_amdgcn_rcpf(dot);
+    const float len = dot * __builtin_amdgcn_rsqf(dot);                   // |D| within a few ulp
+    const float Kf = (float)K;
+    const float slack = len * 0x1p-21f;
+    const float Gx = gx + slack, Gy = gy + slack, Gz = gz + slack;
+    const float R = Kf * ((Gx + Gy) + Gz);
+    const bool ok = R * 4.0f <= len;                                      // false for NaN / inf / tiny directions
+    const float rho = (R * 1.002f) * __builtin_amdgcn_rcpf(len);          // >= R / |D|
+    const float shrink = __builtin_amdgcn_rcpf(1.0f - rho);               // 1 / (1 - rho), rho <= 0.2505
+    const float Q = ((rc * 1.002f) * (shrink * shrink)) * 0x42000000p0f;
+    const float ex = r.dx * invx, ey = r.dy * invy, ez = r.dz * invz;
+    const float ax = __builtin_fabsf(invx) * (Kf * Gx), ay = __builtin_fabsf(invy) * (Kf * Gy), az = __builtin_fabsf(invz) * (Kf * Gz);
+    const float dn_scale = 0.99987f;                                      // 1 - 2^-13
+    auto lim = [&](float e, float a, uint32_t room_up, uint32_t room_dn) {
+        const float up = fma_(fmaxf(e, 0.0f) + a, Q, 0.5f), dn = fma_(fmaxf(-e, 0.0f) + a, Q, 0.5f);
+        const float nu = ((float)room_up * dn_scale) * __builtin_amdgcn_rcpf(up);
+        const float nd = ((float)room_dn * dn_scale) * __builtin_amdgcn_rcpf(dn);
+        return fminf(nu, nd);
+    };
+    float n = lim(ex, ax, hx - r.px, r.px);
+    n = fminf(n, lim(ey, ay, hy - r.py, r.py));
+    n = fminf(n, lim(ez, az, hz - r.pz, r.pz));
+    n = fminf(n, 1.0e6f);
+    const uint32_t steps = (uint32_t)n + 1u;                              // positions before steps 0 .. floor(n) are inside
+    const bool inside = r.px <= hx && r.py <= hy && r.pz <= hz;           // holds by construction of the brick; cheap to assert
+    return (ok && inside && n >= 0.0f) ? steps : 1u;
+}
+
 // The LDS brick always holds fp32 voxels: an int16 field is converted once while it is staged
 // (exact: (float)int16), not 32 times per step.
 __device__ __forceinline__ vox_f32 to_f32_vox(const vox_f32 &v) { return v; }
@@ -175,6 +230,17 @@ template <typename V> __device__ __forceinline__ V to_lds_vox(const V &v) { retu
 template <typename FieldT> struct LdsVox { using type = vox_f32; };
 template <typename V> __device__ __forceinline__ vox_f32 to_lds_vox(const V &v) { return to_f32_vox(v); }
 #endif
+
+// LDS addresses as 32-bit integers (so that they can be pinned in registers ahead of the reads without losing the
+// address space: a generic pointer would turn ds_read into flat_load)
+template <typename LV> __device__ __forceinline__ uint32_t lds_addr(const LV *seg, uint32_t idx)
+{
+    return (uint32_t)(size_t)(__attribute__((address_space(3))) const LV *)seg + idx * (uint32_t)sizeof(LV);
+}
+template <typename LV> __device__ __forceinline__ __attribute__((address_space(3))) const LV *lds_at(uint32_t a)
+{
+    return (__attribute__((address_space(3))) const LV *)(size_t)a;
+}
 
 template <typename LV>
 __device__ __forceinline__ void gather_lds(const LV *seg, uint32_t base, uint32_t sy, uint32_t sx, f4 (&c)[8])
@@ -402,11 +468,50 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                 // Without the opacity test a ray can stop inside a round only by leaving the brick or by using up its
                 // iterations; the round is capped at the smallest remaining count, so "has iterations left" is a
                 // per-round constant there and costs no compare per step (absorption mode can darken a ray mid-round: kDies).
-                const bool pos0 = it > 0;
+                // (lanes that have left the field hold it > 0 but never march again: they are outside the clipped brick.
+                // They are excluded here, or a departed lane with a small count would cap every later round.)
+                const bool pos0 = live;
                 int Kr = Ku;
                 if constexpr (!kDies) {
                     const uint32_t min_it = sgpr(__ockl_wfred_min_u32(pos0 ? it : 0xFFFFFFFFu));
                     Kr = (uint32_t)Ku < min_it ? Ku : (int)min_it;
+#ifndef VRT_SLAB_NO_PROOF
+                    // proven part of the round: no lane can leave the brick during Kg steps (safe_steps), so the loop
+                    // carries no brick test, no ballot and no exit -- lanes not live at the start of the round stay masked
+                    const uint32_t mine = pos0 ? safe_steps(r, invx, invy, invz, p.gstep[0], p.gstep[1], p.gstep[2], Ku,
+                                                             (ex1 << 16) - 1u, (ey1 << 16) - 1u, (ez1 << 16) - 1u)
+                                               : 0xFFFFFFFFu;
+                    uint32_t Kg = sgpr(__ockl_wfred_min_u32(mine));
+                    Kg = Kg < (uint32_t)Kr ? Kg : (uint32_t)Kr;
+                    if (Kg >= (uint32_t)kSlabMinSafe) {
+                        stat_add(p, kStatProvenRounds, 1);
+                        stat_add(p, kStatProvenSteps, Kg);
+                        stat_add(p, kStatLdsWaveSteps, Kg);
+                        VRT_TL(tl_lds += Kg);
+                        if (pos0) {
+                            const uint32_t sy16 = sy * (uint32_t)sizeof(lvox), sx16 = sx * (uint32_t)sizeof(lvox);
+                            for (uint32_t k = 0; k < Kg; ++k) {
+                                // everything the eight reads need (four addresses) and everything that would otherwise be
+                                // computed into a register one of them is still writing (the weights) comes first, so the
+                                // reads issue back to back and nothing waits on a write-after-read of a load in flight
+                                uint32_t a0 = lds_addr(seg, mad24(mad24(r.px >> 16, ey, r.py >> 16), ez, r.pz >> 16));
+                                uint32_t a1 = a0 + sy16, a2 = a0 + sx16, a3 = a2 + sy16;
+                                Weights w = lerp_weights(r);
+                                asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(w.wrx), "+v"(w.wlx), "+v"(w.wry),
+                                             "+v"(w.wly), "+v"(w.wrz), "+v"(w.wlz) :: "memory");
+                                lvox v[8];
+                                v[0] = lds_at<lvox>(a0)[0]; v[1] = lds_at<lvox>(a0)[1]; v[2] = lds_at<lvox>(a1)[0]; v[3] = lds_at<lvox>(a1)[1];
+                                v[4] = lds_at<lvox>(a2)[0]; v[5] = lds_at<lvox>(a2)[1]; v[6] = lds_at<lvox>(a3)[0]; v[7] = lds_at<lvox>(a3)[1];
+                                f4 c[8];
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) cvt_vox(v[q], c[q]);
+                                march_step_now(r, c, w, invx, invy, invz, win);
+                            }
+                            it -= Kg;
+                        }
+                        Kr -= (int)Kg;                   // whatever the plan allowed beyond the proof runs with the tests below
+                    }
+#endif
                 }
                 const uint64_t m_pos0 = lane_mask(pos0);
                 for (int k = 0; k < Kr; ++k) {
@@ -481,6 +586,19 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
         light = 0xFFFFFFFFu;
     };
 
+    // wave 0 of block 0 notes the shader clock (s_memtime) against the 100 MHz wall clock (s_memrealtime) around its
+    // whole life: the clock the kernel really ran at (bench.py prices the VALU-issue roofline with it)
+    const bool stamps = p.clock_out != nullptr && blockIdx.x == 0 && threadIdx.x < 64;
+    unsigned long long ck_t0 = 0, ck_r0 = 0;
+    if (stamps) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ck_t0), "=s"(ck_r0) :: "memory");
+    auto clock_stamp_end = [&]() {
+        if (stamps) {
+            unsigned long long t1, r1;
+            asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) :: "memory");
+            if (lane == 0) { p.clock_out[0] = ck_t0; p.clock_out[1] = ck_r0; p.clock_out[2] = t1; p.clock_out[3] = r1; }
+        }
+    };
+
     if constexpr (!PERSIST) {
         // one wavefront per group of 64 slots; the hardware dispatcher hands out groups in launch order
         begin_group(launch_slot(p) & ~63u);
@@ -542,6 +660,7 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
         ph_flush();
 #endif
     }
+    clock_stamp_end();
 #undef VRT_TL
 }
 
@@ -552,7 +671,11 @@ hipError_t launch_slab_vpl(const MarchParams &p, int num_cu, hipStream_t s)
     const unsigned groups_blocks = (p.nrays + threads - 1) / threads;
     const size_t lds = sizeof(typename LdsVox<FieldT>::type) * 64 * VPL * kSlabWavesPerBlock;
     constexpr size_t seg_bytes = sizeof(typename LdsVox<FieldT>::type) * 64 * VPL;
+#ifdef VRT_SLAB_EXPERIMENT    // development builds: every segment size has the persistent variant (A/B of LDS sizes)
+    constexpr bool kHasPersist = true;
+#else
     constexpr bool kHasPersist = seg_bytes == 6144 || seg_bytes == 8192;    // launch_slab sends persistent launches only here
+#endif
     if constexpr (kHasPersist) if (p.group_counter) {
         // persistent grid: the wavefronts the GPU holds at once (OCC per SIMD = OCC blocks of 4 wavefronts per CU)
         const unsigned resident = (unsigned)(num_cu > 0 ? num_cu : 256) * (unsigned)OCC;
@@ -592,14 +715,17 @@ hipError_t launch_slab(MarchParams p, bool /*path*/, int num_cu, hipStream_t s)
         if (want <= 6144) return launch_slab_bytes<FieldT, DirT, 6144, 6, true>(p, num_cu, s);
         return launch_slab_bytes<FieldT, DirT, 8192, 5, true>(p, num_cu, s);
     }
+#ifndef VRT_SLAB_EXPERIMENT
     if (p.group_counter || want == 6144 || want == 8192) { // the persistent variant exists for the two default sizes
         if (want <= 6144) return launch_slab_bytes<FieldT, DirT, 6144, 6>(p, num_cu, s);
         return launch_slab_bytes<FieldT, DirT, 8192, 5>(p, num_cu, s);
     }
+#endif
     if (want <= 4096) return launch_slab_bytes<FieldT, DirT, 4096, 8>(p, num_cu, s);
     if (want <= 5120) return launch_slab_bytes<FieldT, DirT, 5120, 7>(p, num_cu, s);
     if (want <= 6144) return launch_slab_bytes<FieldT, DirT, 6144, 6>(p, num_cu, s);
     if (want <= 8192) return launch_slab_bytes<FieldT, DirT, 8192, 5>(p, num_cu, s);
+    if (want <= 10240) return launch_slab_bytes<FieldT, DirT, 10240, 4>(p, num_cu, s);
     if (want <= 12288) return launch_slab_bytes<FieldT, DirT, 12288, 3>(p, num_cu, s);
     return launch_slab_bytes<FieldT, DirT, 16384, 2>(p, num_cu, s);
 }
