@@ -12,8 +12,15 @@ same number of rays).
 
 Prints ONE JSON line on rank 0 (see DESIGN.md §Measurement for the definitions):
   value            = sum(end_iteration over all rays of all ranks) * K / wall time   [ray-steps/s]
-  roofline.achieved= 128 B (fp32 field; 64 B int16) * ray-steps of one launch / HIP-event
-                     duration of the march kernel, averaged over the K timed launches of rank 0
+  roofline         = the march kernel against the resource that binds it.  The corners of the gather come out of LDS,
+                     so HBM does not bind this kernel; vector-ALU issue does.  frac = achieved / peak <= 1 with
+                       achieved = SQ_INSTS_VALU per launch (profiles/roofline_inputs.json, rocprofv3 counter pass of the
+                                  same workload) / HIP-event duration of the kernel measured live in this run
+                       peak     = SIMDs x shader clock / 2 (a wave64 instruction issues over two cycles of a SIMD-32),
+                                  the clock measured live inside the kernel (s_memtime / s_memrealtime)
+                     next to it: roofline.lds, roofline.hbm_measured (counter bytes) and roofline.hbm_algorithmic, the
+                     contract's 128 B (fp32 field; 64 B int16) per ray-step figure, which exceeds the HBM peak because
+                     the bytes are served from LDS -- reported, but not a bound
   cpu_baseline     = the oracle (oracle/vrt_oracle.c, "port") or the real reference build
                      (oracle/_ref, "reference") on a bounded sample of the same rays, same field
 """
@@ -179,6 +186,55 @@ def cpu_baseline(field_host, bounds, sp, sd, inv, iterations, gpu_out, budget_s,
     return res
 
 
+def roofline_object(args, cfg, dev, eng, ray_steps, kernel_ms, clocks, bytes_per_step):
+    """The march kernel against its binding resource (module docstring).  Counter-derived inputs come from
+    profiles/roofline_inputs.json and are used only when that profile was taken on this very workload (same number of
+    ray-steps per launch); time and clock are measured in this run."""
+    t = kernel_ms * 1e-3
+    props = torch.cuda.get_device_properties(dev)
+    simds = props.multi_processor_count * 4
+    clock = float(np.mean(clocks)) * 1e9 if clocks else None
+    inp, src = None, None
+    try:
+        inp = json.load(open(args.roofline_inputs)).get("config%d" % args.config)
+        src = os.path.relpath(args.roofline_inputs, ROOT)
+    except Exception:
+        inp = None
+    same = bool(inp) and inp.get("ray_steps") == ray_steps and args.kernel == "auto" and args.lds_bytes == 0 and args.sort == 0
+    alg = ray_steps * bytes_per_step / t / 1e9
+    out = {"bound": "valu-issue", "achieved": None, "peak": None, "unit": "Gwave-instr/s", "frac": None,
+           "traffic": None, "traffic_source": None, "kernel_ms": kernel_ms, "clock_ghz": clock / 1e9 if clock else None,
+           "clock_source": "s_memtime / s_memrealtime of one wavefront of the march kernel, this run",
+           "simds": simds,
+           "hbm_algorithmic": {"achieved": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / HBM_PEAK_GBS,
+                               "bytes_per_ray_step": bytes_per_step,
+                               "note": "SURVEY 8(d) figure; exceeds 1 because the gather is served from LDS, not HBM: not a bound"},
+           "compulsory_bytes": eng.field_bytes, "measured_copy_GBps": device_copy_gbs(dev)}
+    if clock:
+        out["peak"] = simds * clock / 2.0 / 1e9
+    if same:
+        out["inputs"] = {"file": src, "profile": inp.get("profile"), "kernel": inp.get("kernel"), "round": inp.get("round"),
+                         "counters": inp.get("counters")}
+        if inp.get("valu_insts") and clock:
+            out["achieved"] = inp["valu_insts"] / t / 1e9
+            out["frac"] = out["achieved"] / out["peak"]
+            out["valu"] = {"insts_per_launch": inp["valu_insts"], "insts_per_64_ray_steps": inp["valu_insts"] / (ray_steps / 64.0),
+                           "lane_utilisation": inp.get("lane_utilisation"), "counter": "SQ_INSTS_VALU", "frac": out["frac"]}
+        if inp.get("lds_insts") and clock:
+            lds_bytes = inp["lds_insts"] * 1024.0                       # a wave-wide ds_read_b128 / ds_write_b128 moves 1 KiB
+            peak = props.multi_processor_count * 256.0 * clock          # 256 B per clock per CU (MI355X_MICROARCH.md, LDS)
+            out["lds"] = {"achieved": lds_bytes / t / 1e9, "peak": peak / 1e9, "unit": "GB/s", "frac": lds_bytes / t / peak,
+                          "bank_conflict_share": inp.get("lds_bank_conflict_share"), "counter": "SQ_INSTS_LDS x 1 KiB"}
+        if inp.get("hbm_bytes"):
+            out["traffic"] = inp["hbm_bytes"]
+            out["traffic_source"] = "%s: %s" % (inp.get("profile"), inp.get("hbm_bytes_formula"))
+            out["hbm_measured"] = {"achieved": inp["hbm_bytes"] / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": inp["hbm_bytes"] / t / 1e9 / HBM_PEAK_GBS, "counter": "FETCH_SIZE, WRITE_SIZE"}
+    else:
+        out["inputs"] = {"file": src, "note": "no counter profile of exactly this workload: counter-derived fractions omitted"}
+    return out
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -216,7 +272,8 @@ def main():
     ap.add_argument("--lds-bytes", type=int, default=0)
     ap.add_argument("--iterations", type=int, default=100000)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget; 0 disables it")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
+    ap.add_argument("--roofline-inputs", default=os.path.join(ROOT, "profiles", "roofline_inputs.json"),
+                    help="per-launch counters of the march kernel from the rocprofv3 passes (tools/collect_profiles.py)")
     ap.add_argument("--no-rebalance", action="store_true", help="N > 1: keep equal-count row bands (no work rebalancing)")
     ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
                     help="N > 1: weak = every rank marches R rows of an (R*N) x R lattice (default); strong = the fixed R x R "
@@ -337,11 +394,12 @@ def main():
 
     # per-launch kernel duration from HIP events on the launch stream: re-run the K launches one by
     # one (same inputs, same kernel) outside the wall-clock region so reading the events adds no sync to it
-    kernel_ms = []
+    kernel_ms, clock_ghz = [], []
     for _ in range(args.steps):
         eng.trace_device(capi.VRT_F32, n, d_sp.data_ptr(), d_sd.data_ptr(), o_ep.data_ptr(), o_ed.data_ptr(),
                          o_ei.data_ptr(), o_rl.data_ptr(), inv, args.iterations, stream=stream, options=opts)
         kernel_ms.append(eng.last_march_ms())
+        clock_ghz.append(eng.last_march_clock_ghz())
     torch.cuda.synchronize()
 
     if os.environ.get("VRT_DEBUG_STATS") == "1" and rank == 0:
@@ -364,14 +422,7 @@ def main():
 
     bytes_per_step = 128 if cfg["field"] == "f32" else 64
     kavg_ms = float(np.mean(kernel_ms))
-    achieved = steps_local * bytes_per_step / (kavg_ms * 1e-3) / 1e9
-    traffic = None
-    if os.path.exists(args.traffic_json):
-        try:
-            tj = json.load(open(args.traffic_json))
-            traffic = tj.get("config%d" % args.config, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    roofline = roofline_object(args, cfg, dev, eng, steps_local, kavg_ms, [c for c in clock_ghz if c > 0], bytes_per_step)
     result = {
         "metric": "ray-steps/sec",
         "value": steps_total * args.steps / elapsed,
@@ -391,10 +442,7 @@ def main():
                                    % (lattice_rows(cfg, world, scaling), cfg["R"], world, "" if args.no_rebalance else " of equal measured work",
                                       "gloo (rehearsal on one GPU, host staging)" if args.rehearse else "RCCL")) if world > 1 else "single GPU",
                    "rays_total": int(sum(counts))},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel_ms": kavg_ms, "algorithmic_bytes_per_ray_step": bytes_per_step,
-                     "compulsory_bytes": eng.field_bytes, "measured_copy_GBps": device_copy_gbs(dev)},
+        "roofline": roofline,
     }
     if args.cpu_seconds > 0 and world == 1:                        # CPU baseline: rank 0 at N = 1 only
         import oracle

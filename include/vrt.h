@@ -59,7 +59,8 @@ typedef struct vrt_options {
     int32_t  kernel;         /* extension: VRT_KERNEL_* selector, 0 = auto */
     int32_t  sort_rays;      /* extension: 0 = auto (3 for >= 4096 rays), 1 = tile ordering, 2 = tile ordering with per-ray length buckets,
                                 3 = tile ordering + wavefronts launched longest-first, -1 = keep caller order */
-    int32_t  slab_lds_bytes; /* extension: LDS bytes per wavefront for the slab kernel, 0 = default */
+    int32_t  slab_lds_bytes; /* extension: LDS bytes per wavefront for the slab kernel, 0 = default (10240, or 6144 for ray sets
+                                denser than 8 rays per voxel column); rounded up to one of 4096 5120 6144 8192 10240 12288 16384 */
     int32_t  absorption;     /* extension, opt-in: 1 = run the absorption branch the reference compiles out
                               * (cuda_volume_raytracer.cu:337-341): per step brightness -= min(brightness,
                               * 0xFFFFFFFF - translucency[voxel]); stop when brightness < min_brightness;

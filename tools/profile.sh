@@ -24,6 +24,7 @@ pass write WRITE_SIZE
 pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY
 pass sq2 SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS
 pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+pass grbm GRBM_GUI_ACTIVE
 # (the tcp pass is optional and slow on some boxes: run it by hand when needed)
 [ "${VRT_PROFILE_TCP:-0}" = 1 ] && pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_BUSY_avr GRBM_GUI_ACTIVE
 echo done

@@ -12,11 +12,13 @@ import json
 import os
 import sys
 
-KEEP = ("k_march", "k_tile_keys", "k_interleave", "radix", "onesweep", "rocprim", "k_wave_work", "k_ray_bounds")
+KEEP = ("k_march", "k_tile_keys", "k_interleave", "radix", "onesweep", "rocprim", "k_wave_work", "k_ray_bounds", "k_scene_build",
+        "k_ray_prologue", "k_field_absmax")
 
 
 def short(name):
-    for k in ("k_march_direct", "k_march_slab", "k_tile_keys", "k_interleave_f32", "k_interleave_i16"):
+    for k in ("k_march_direct", "k_march_slab", "k_tile_keys", "k_interleave_f32", "k_interleave_i16", "k_scene_build", "k_ray_prologue",
+              "k_field_absmax"):
         if k in name:
             # keep template arguments readable
             i = name.find(k)

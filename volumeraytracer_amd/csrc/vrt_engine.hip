@@ -324,11 +324,11 @@ void engine_free(vrt_engine *e)
 // ---- launch ---------------------------------------------------------------------------------
 
 template <typename FieldT, typename DirT>
-int launch_typed(vrt_engine *e, const vrt::MarchParams &p, int kernel, hipStream_t s)
+int launch_typed(vrt_engine *e, const vrt::MarchParams &p, int kernel, vrt::SlabGeometry geo, hipStream_t s)
 {
     const bool path = p.path != nullptr;
     if (kernel == VRT_KERNEL_SLAB) {
-        const hipError_t le = vrt::launch_slab<FieldT, DirT>(p, path, e->num_cu, s);   // (hipGetLastError() clears the error it returns)
+        const hipError_t le = vrt::launch_slab<FieldT, DirT>(p, geo, e->num_cu, s);   // (hipGetLastError() clears the error it returns)
         return le == hipSuccess ? VRT_OK : fail(VRT_ERR_HIP, "slab kernel launch failed: %s", hipGetErrorString(le));
     }
     const unsigned grid = (p.nrays + 255) / 256;
@@ -428,14 +428,18 @@ int trace_device_impl(vrt_engine *e, Workspace &w, int dir_type, size_t nrays, c
         return fail(VRT_ERR_INVALID_ARGUMENT, "unknown kernel selector %d", kernel);
     if (kernel == VRT_KERNEL_SLAB && d_path) kernel = VRT_KERNEL_DIRECT;   // path tracing is write-bound: direct kernel
 
+    // slab kernel geometry: LDS segment per wavefront -> wavefronts resident per CU (vrt_slab.h, slab_geometry)
+    const vrt::SlabGeometry geo = vrt::slab_geometry(p.slab_lds_bytes, p.nrays, p.Bx, p.By, p.Bz);
+    const size_t resident_waves = (size_t)e->num_cu * 4 * (size_t)geo.occ;
+
     // tile ordering: group rays that enter the field close together into the same wavefront
     const bool sort = o.sort_rays > 0 || (o.sort_rays == 0 && nrays >= 4096);
     if (sort) {
         Range range("vrt: ray order");
         const uint32_t *order = nullptr, *wave_order = nullptr;
         // longest wavefronts first: always for 3; in auto mode only when the launch has more wavefronts than the
-        // GPU holds at once (24 per CU at the default LDS segment) -- otherwise every wavefront starts at t = 0 anyway
-        const int wave_lpt = !d_path && (o.sort_rays == 3 || (o.sort_rays == 0 && (nrays + 63) / 64 > (size_t)e->num_cu * 24));
+        // GPU holds at once -- otherwise every wavefront starts at t = 0 anyway
+        const int wave_lpt = !d_path && (o.sort_rays == 3 || (o.sort_rays == 0 && (nrays + 63) / 64 > resident_waves));
         hipError_t se = vrt::build_tile_order(d_sp, d_sd, dir_type, (uint32_t)nrays, e->B[0], e->B[1], e->B[2], o.sort_rays == 2 ? 1 : 0, w.sort_keys, w.sort_keys_alt,
                                               w.sort_vals, w.sort_vals_alt, w.sort_tmp, w.sort_bounds, s, &order,
                                               wave_lpt, iterations, &wave_order, e->field, e->field_type == VRT_I16, invscale);
@@ -454,8 +458,8 @@ int trace_device_impl(vrt_engine *e, Workspace &w, int dir_type, size_t nrays, c
         if (const char *ev = getenv("VRT_SCHEDULE"); ev && schedule == 0) schedule = atoi(ev);
         if (schedule < 0 || schedule > 2) return fail(VRT_ERR_INVALID_ARGUMENT, "unknown schedule %d", schedule);
         // auto: persistent once the launch has more wavefronts than the GPU holds (measured -4 % on config 3)
-        if (schedule == 0) schedule = groups > (size_t)e->num_cu * 24 ? 2 : 1;
-        if (schedule == 2 && kernel == VRT_KERNEL_SLAB && groups > 1) {
+        if (schedule == 0) schedule = groups > resident_waves ? 2 : 1;
+        if (schedule == 2 && kernel == VRT_KERNEL_SLAB && groups > 1 && geo.complete) {
             HIP_TRY(w.group_ctr.reserve(sizeof(uint32_t)));
             HIP_TRY(hipMemsetAsync(w.group_ctr.p, 0, sizeof(uint32_t), s));
             p.group_counter = (uint32_t *)w.group_ctr.p;
@@ -472,9 +476,9 @@ int trace_device_impl(vrt_engine *e, Workspace &w, int dir_type, size_t nrays, c
     HIP_TRY(hipEventRecord(w.ev_begin, s));
     int rc;
     if (e->field_type == VRT_F32)
-        rc = dir_type == VRT_F32 ? launch_typed<float, float>(e, p, kernel, s) : launch_typed<float, int16_t>(e, p, kernel, s);
+        rc = dir_type == VRT_F32 ? launch_typed<float, float>(e, p, kernel, geo, s) : launch_typed<float, int16_t>(e, p, kernel, geo, s);
     else
-        rc = dir_type == VRT_F32 ? launch_typed<int16_t, float>(e, p, kernel, s) : launch_typed<int16_t, int16_t>(e, p, kernel, s);
+        rc = dir_type == VRT_F32 ? launch_typed<int16_t, float>(e, p, kernel, geo, s) : launch_typed<int16_t, int16_t>(e, p, kernel, geo, s);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(w.ev_end, s));
     HIP_TRY(hipEventRecord(w.ev_done, s));

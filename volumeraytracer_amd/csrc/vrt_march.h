@@ -122,6 +122,9 @@ struct Ray {
 
 // check_w == false promises that none of the eight corners has w > 0 (the slab kernel knows this for a
 // whole brick from a ballot taken while staging it), so the opacity test cannot fire and is skipped.
+// PRESCALED: the x, y, z channels of the corners already carry the interpolation's factor 2^-48 (the slab kernel
+// scales them once while staging a brick, exactly -- see stage_scale_ok in vrt_slab.h); the w channel is always raw.
+template <bool PRESCALED = false>
 __device__ __forceinline__ bool march_step(Ray &r, const f4 (&c)[8], float invx, float invy, float invz,
                                            StepWindow win, bool check_w = true)
 {
@@ -157,7 +160,8 @@ __device__ __forceinline__ bool march_step(Ray &r, const f4 (&c)[8], float invx,
         a00 = lerp_(c[0].ch, wlx, c[4].ch, wrx); a01 = lerp_(c[1].ch, wlx, c[5].ch, wrx);        \
         a10 = lerp_(c[2].ch, wlx, c[6].ch, wrx); a11 = lerp_(c[3].ch, wlx, c[7].ch, wrx);        \
         b0 = lerp_(a00, wly, a10, wry); b1 = lerp_(a01, wly, a11, wry);                          \
-        out = lerp_(b0, wlz, b1, wrz) * (1.0f / 0x1000000000000p0f);
+        out = lerp_(b0, wlz, b1, wrz);                                                           \
+        if constexpr (!PRESCALED) out *= (1.0f / 0x1000000000000p0f);
         VRT_CH(x, g[0]) VRT_CH(y, g[1]) VRT_CH(z, g[2])
 #undef VRT_CH
     }
@@ -201,6 +205,9 @@ __device__ __forceinline__ Weights lerp_weights(const Ray &r)
     w.wrz = (float)(r.pz & 0xFFFFu); w.wlz = 65536.0f - w.wrz;
     return w;
 }
+// WINDOW_TEST = false: the caller has proven that |dir|^2 stays inside the fast-path window for the whole round
+// (safe_steps, vrt_slab.h), so the step carries no test at all.
+template <bool PRESCALED, bool WINDOW_TEST>
 __device__ __forceinline__ void march_step_now(Ray &r, const f4 (&c)[8], const Weights &w, float invx, float invy, float invz, StepWindow win)
 {
     const float wrx = w.wrx, wlx = w.wlx, wry = w.wry, wly = w.wly, wrz = w.wrz, wlz = w.wlz;
@@ -211,7 +218,8 @@ __device__ __forceinline__ void march_step_now(Ray &r, const f4 (&c)[8], const W
         a00 = lerp_(c[0].ch, wlx, c[4].ch, wrx); a01 = lerp_(c[1].ch, wlx, c[5].ch, wrx);        \
         a10 = lerp_(c[2].ch, wlx, c[6].ch, wrx); a11 = lerp_(c[3].ch, wlx, c[7].ch, wrx);        \
         b0 = lerp_(a00, wly, a10, wry); b1 = lerp_(a01, wly, a11, wry);                          \
-        out = lerp_(b0, wlz, b1, wrz) * (1.0f / 0x1000000000000p0f);
+        out = lerp_(b0, wlz, b1, wrz);                                                           \
+        if constexpr (!PRESCALED) out *= (1.0f / 0x1000000000000p0f);
         VRT_CH(x, g[0]) VRT_CH(y, g[1]) VRT_CH(z, g[2])
 #undef VRT_CH
     }
@@ -222,7 +230,7 @@ __device__ __forceinline__ void march_step_now(Ray &r, const f4 (&c)[8], const W
     const float ex = r.dx * invx, ey = r.dy * invy, ez = r.dz * invz;
     const float ilen2 = ilen2_short(dot);                   // garbage outside the window, replaced below
     uint32_t sx = round_half_i32(ex * ilen2), sy = round_half_i32(ey * ilen2), sz = round_half_i32(ez * ilen2);
-    const bool outside = !((__float_as_uint(dot) - win.lo) < win.span);
+    const bool outside = WINDOW_TEST && !((__float_as_uint(dot) - win.lo) < win.span);
     if (outside) {                                          // rare: skipped by one scalar branch when no lane needs it
         const float ilen = 0x42000000p0f / dot;
         const float il2 = ilen + ilen;

@@ -181,8 +181,12 @@ __device__ __forceinline__ uint32_t plan_brick(const PlanIn &in, int K, const ui
 // j * up_d <= H_d - 1 - p_d and j * dn_d <= p_d.  The divisions are evaluated with v_rcp_f32 and scaled down by
 // (1 - 2^-13), far more than the three roundings involved; a NaN or infinite direction fails `ok` and yields 1 (the
 // position the lane has now is inside the brick by construction).
+// The same bound proves the fast-path window of the step (StepWindow): |D| stays within [3/4, 5/4] of its present
+// value for K steps, so dot stays within [0.5625, 1.5625] dot (1 +- 2^-21); if [0.55, 1.6] dot lies strictly inside
+// the window now, no step of the round can leave it and the loop needs no window test (`window_ok`).
 __device__ __forceinline__ uint32_t safe_steps(const Ray &r /* relative to the brick origin */, float invx, float invy, float invz,
-                                               float gx, float gy, float gz, int K, uint32_t hx, uint32_t hy, uint32_t hz /* H_d - 1 */)
+                                               float gx, float gy, float gz, int K, uint32_t hx, uint32_t hy, uint32_t hz /* H_d - 1 */,
+                                               StepWindow win, bool &window_ok)
 {
     const float dot = fma_(r.dz, r.dz, fma_(r.dx, r.dx, r.dy * r.dy));
     const float rc = __builtin_amdgcn_rcpf(dot);
@@ -210,6 +214,8 @@ __device__ __forceinline__ uint32_t safe_steps(const Ray &r /* relative to the b
     n = fminf(n, 1.0e6f);
     const uint32_t steps = (uint32_t)n + 1u;                              // positions before steps 0 .. floor(n) are inside
     const bool inside = r.px <= hx && r.py <= hy && r.pz <= hz;           // holds by construction of the brick; cheap to assert
+    // window bounds as floats: bit patterns in [lo, lo + span) are positive finite floats, ordered like their patterns
+    window_ok = ok && win.span != 0u && dot * 0.55f >= __uint_as_float(win.lo) && dot * 1.6f < __uint_as_float(win.lo + win.span - 1u);
     return (ok && inside && n >= 0.0f) ? steps : 1u;
 }
 
@@ -223,12 +229,36 @@ __device__ __forceinline__ vox_f32 to_f32_vox(const vox_i16 &v)
     return o;
 }
 
-#ifndef VRT_SLAB_LDS_F32   // default: keep the field's own voxel type in LDS (measured: config 5 is 2% faster than fp32-in-LDS)
+// fp32 bricks are stored PRESCALED: x, y, z carry the interpolation's final factor 2^-48 (.cu:154), so the step
+// does not multiply three results by it.  Scaling by a power of two commutes with every rounding of the nested lerps as
+// long as no intermediate of the scaled computation is subnormal.  With all non-zero inputs at least 2^-55 in magnitude
+// every intermediate of the unscaled computation is a multiple of 2^-78 (products with the integer weights and their
+// sums keep that grid, and rounding a multiple of 2^-78 to 24 bits keeps it too), hence zero or at least 2^-78 and, scaled,
+// zero or at least 2^-126: normal.  prescale_ok() is that input condition; a brick that fails it is not staged
+// (the round gathers from global memory, unscaled), which is what keeps the results bit-identical.
+__device__ __forceinline__ bool prescale_ok(const vox_f32 &v)
+{
+    auto ok = [](float a) { const uint32_t b = __float_as_uint(a) & 0x7FFFFFFFu; return b == 0u || b >= ((127u - 55u) << 23); };
+    return ok(v.x) && ok(v.y) && ok(v.z);                 // (NaN / inf pass: they are NaN / inf either way)
+}
+__device__ __forceinline__ bool prescale_ok(const vox_i16 &) { return true; }   // |v| >= 1 or 0
+__device__ __forceinline__ vox_f32 prescaled(vox_f32 v)
+{
+    const float s = 1.0f / 0x1000000000000p0f;
+    v.x *= s; v.y *= s; v.z *= s;                          // w stays raw: only its sign is ever used
+    return v;
+}
+// Bricks hold fp32 voxels for both field types: an int16 field is converted (exactly) while it is staged, once per
+// voxel and round instead of 32 conversions per step.  Measured on config 5 (int16 field) at the 10 KiB segment:
+// fp32 bricks 14.9 ms, int16 bricks of twice the voxel count 15.2 ms; at equal bytes the conversions cost more than
+// the smaller brick (development builds with -DVRT_SLAB_LDS_FIELD keep the field's own type in LDS for comparison).
+#ifdef VRT_SLAB_LDS_FIELD
 template <typename FieldT> struct LdsVox { using type = typename FieldTraits<FieldT>::vox; };
-template <typename V> __device__ __forceinline__ V to_lds_vox(const V &v) { return v; }
+__device__ __forceinline__ vox_f32 to_lds_vox(const vox_f32 &v) { return prescaled(v); }
+__device__ __forceinline__ vox_i16 to_lds_vox(const vox_i16 &v) { return v; }
 #else
 template <typename FieldT> struct LdsVox { using type = vox_f32; };
-template <typename V> __device__ __forceinline__ vox_f32 to_lds_vox(const V &v) { return to_f32_vox(v); }
+template <typename V> __device__ __forceinline__ vox_f32 to_lds_vox(const V &v) { return prescaled(to_f32_vox(v)); }
 #endif
 
 // LDS addresses as 32-bit integers (so that they can be pinned in registers ahead of the reads without losing the
@@ -265,6 +295,7 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t wave = threadIdx.x >> 6;
     using lvox = typename LdsVox<FieldT>::type;
+    constexpr bool kPrescaled = sizeof(lvox) == 16;     // fp32 bricks carry the 2^-48 (see prescale_ok)
     lvox *seg = (lvox *)smem + (size_t)wave * kCap;
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -358,8 +389,57 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
         }
 
         VRT_PH(kPhPlan);
-        if (vol > kCap || K < kSlabMinK || bk.e[0] < 2 || bk.e[1] < 2 || bk.e[2] < 2) {
-            // ---- incoherent wave: gather from global memory for a few steps, then re-plan ----
+        const uint32_t ey = bk.e[1], ez = bk.e[2];
+        bool brick_has_w = false;
+        bool staged = false;
+        // ---- stage: brick -> LDS ----------------------------------------------------------
+        if (!(vol > kCap || K < kSlabMinK || bk.e[0] < 2 || bk.e[1] < 2 || bk.e[2] < 2)) {
+            // exact division by the wave-uniform extents via 2^32 reciprocals (v < 2^16)
+            const uint32_t mz = (uint32_t)(0x100000000ull / ez) + 1u;     // ez >= 2
+            const uint32_t my = (uint32_t)(0x100000000ull / ey) + 1u;     // ey >= 2
+            const size_t gsy = p.Bz, gsx = (size_t)p.By * p.Bz;
+            const vox *g0 = f + ((size_t)bk.lo[0] * p.By + bk.lo[1]) * p.Bz + bk.lo[2];
+            vox tmp[VPL];
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                const uint32_t v = lane + 64u * j;
+                const uint32_t vc = v < vol ? v : 0u;                 // clamp: lanes past the end re-read voxel 0
+                const uint32_t t = __umulhi(vc, mz);                  // vc / ez
+                const uint32_t lz = vc - t * ez;
+                const uint32_t lx = __umulhi(t, my);                  // t / ey
+                const uint32_t ly = t - lx * ey;
+                tmp[j] = g0[(size_t)lx * gsx + (size_t)ly * gsy + lz];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");    // previous round's LDS reads are done
+            bool wpos = false, tiny = false;
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                wpos |= tmp[j].w > 0;                                 // lanes past the end re-read voxel 0: harmless
+                if constexpr (kPrescaled) tiny |= !prescale_ok(tmp[j]);
+            }
+            // fp32 bricks carry the interpolation's 2^-48 (three multiplications less per step); a brick holding a value
+            // too small for that to be exact (prescale_ok) is not staged at all: the round gathers from global memory
+            staged = !kPrescaled || !any_lane(tiny);
+            if (staged) {
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) {
+                    const uint32_t v = lane + 64u * j;
+                    if (v < vol) seg[v] = to_lds_vox(tmp[j]);
+                }
+                brick_has_w = any_lane(wpos);                     // wave-uniform: any opaque-ish voxel staged?
+                stat_add(p, kStatRounds, 1);
+                VRT_TL(++tl_rounds);
+                stat_add(p, kStatPlannedK, (unsigned long long)K);
+                stat_add(p, kStatVoxStaged, vol);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        VRT_PH(kPhStage);
+
+        if (!staged) {
+            // ---- incoherent wave (or a brick that cannot be staged exactly): gather from global memory for a few
+            // steps, then re-plan ----
             stat_add(p, kStatDirectRounds, 1);
             VRT_TL(++tl_rounds);
 #ifdef VRT_SLAB_STATS
@@ -412,44 +492,6 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
             continue;
         }
 
-        stat_add(p, kStatRounds, 1);
-        VRT_TL(++tl_rounds);
-        stat_add(p, kStatPlannedK, (unsigned long long)K);
-        stat_add(p, kStatVoxStaged, vol);
-        const uint32_t ey = bk.e[1], ez = bk.e[2];
-        bool brick_has_w;
-        // ---- stage: brick -> LDS ----------------------------------------------------------
-        {
-            // exact division by the wave-uniform extents via 2^32 reciprocals (v < 2^16)
-            const uint32_t mz = (uint32_t)(0x100000000ull / ez) + 1u;     // ez >= 2
-            const uint32_t my = (uint32_t)(0x100000000ull / ey) + 1u;     // ey >= 2
-            const size_t gsy = p.Bz, gsx = (size_t)p.By * p.Bz;
-            const vox *g0 = f + ((size_t)bk.lo[0] * p.By + bk.lo[1]) * p.Bz + bk.lo[2];
-            vox tmp[VPL];
-#pragma unroll
-            for (int j = 0; j < VPL; ++j) {
-                const uint32_t v = lane + 64u * j;
-                const uint32_t vc = v < vol ? v : 0u;                 // clamp: lanes past the end re-read voxel 0
-                const uint32_t t = __umulhi(vc, mz);                  // vc / ez
-                const uint32_t lz = vc - t * ez;
-                const uint32_t lx = __umulhi(t, my);                  // t / ey
-                const uint32_t ly = t - lx * ey;
-                tmp[j] = g0[(size_t)lx * gsx + (size_t)ly * gsy + lz];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");    // previous round's LDS reads are done
-            bool wpos = false;
-#pragma unroll
-            for (int j = 0; j < VPL; ++j) {
-                const uint32_t v = lane + 64u * j;
-                wpos |= tmp[j].w > 0;                                 // lanes past the end re-read voxel 0: harmless
-                if (v < vol) seg[v] = to_lds_vox(tmp[j]);
-            }
-            brick_has_w = any_lane(wpos);                     // wave-uniform: any opaque-ish voxel staged?
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-        VRT_PH(kPhStage);
-
         // ---- march: up to K steps out of LDS ------------------------------------------------
         {
             const uint32_t sy = ez, sx = ey * ez;
@@ -478,9 +520,11 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
 #ifndef VRT_SLAB_NO_PROOF
                     // proven part of the round: no lane can leave the brick during Kg steps (safe_steps), so the loop
                     // carries no brick test, no ballot and no exit -- lanes not live at the start of the round stay masked
+                    bool win_mine = true;
                     const uint32_t mine = pos0 ? safe_steps(r, invx, invy, invz, p.gstep[0], p.gstep[1], p.gstep[2], Ku,
-                                                             (ex1 << 16) - 1u, (ey1 << 16) - 1u, (ez1 << 16) - 1u)
+                                                             (ex1 << 16) - 1u, (ey1 << 16) - 1u, (ez1 << 16) - 1u, win, win_mine)
                                                : 0xFFFFFFFFu;
+                    const bool win_all = !any_lane(pos0 && !win_mine);
                     uint32_t Kg = sgpr(__ockl_wfred_min_u32(mine));
                     Kg = Kg < (uint32_t)Kr ? Kg : (uint32_t)Kr;
                     if (Kg >= (uint32_t)kSlabMinSafe) {
@@ -490,23 +534,26 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                         VRT_TL(tl_lds += Kg);
                         if (pos0) {
                             const uint32_t sy16 = sy * (uint32_t)sizeof(lvox), sx16 = sx * (uint32_t)sizeof(lvox);
-                            for (uint32_t k = 0; k < Kg; ++k) {
-                                // everything the eight reads need (four addresses) and everything that would otherwise be
-                                // computed into a register one of them is still writing (the weights) comes first, so the
-                                // reads issue back to back and nothing waits on a write-after-read of a load in flight
-                                uint32_t a0 = lds_addr(seg, mad24(mad24(r.px >> 16, ey, r.py >> 16), ez, r.pz >> 16));
-                                uint32_t a1 = a0 + sy16, a2 = a0 + sx16, a3 = a2 + sy16;
-                                Weights w = lerp_weights(r);
-                                asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(w.wrx), "+v"(w.wlx), "+v"(w.wry),
-                                             "+v"(w.wly), "+v"(w.wrz), "+v"(w.wlz) :: "memory");
-                                lvox v[8];
-                                v[0] = lds_at<lvox>(a0)[0]; v[1] = lds_at<lvox>(a0)[1]; v[2] = lds_at<lvox>(a1)[0]; v[3] = lds_at<lvox>(a1)[1];
-                                v[4] = lds_at<lvox>(a2)[0]; v[5] = lds_at<lvox>(a2)[1]; v[6] = lds_at<lvox>(a3)[0]; v[7] = lds_at<lvox>(a3)[1];
-                                f4 c[8];
+                            auto proven = [&](auto window_test) {
+                                for (uint32_t k = 0; k < Kg; ++k) {
+                                    // everything the eight reads need (four addresses) and everything that would otherwise be
+                                    // computed into a register one of them is still writing (the weights) comes first, so the
+                                    // reads issue back to back and nothing waits on a write-after-read of a load in flight
+                                    uint32_t a0 = lds_addr(seg, mad24(mad24(r.px >> 16, ey, r.py >> 16), ez, r.pz >> 16));
+                                    uint32_t a1 = a0 + sy16, a2 = a0 + sx16, a3 = a2 + sy16;
+                                    Weights w = lerp_weights(r);
+                                    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(w.wrx), "+v"(w.wlx), "+v"(w.wry),
+                                                 "+v"(w.wly), "+v"(w.wrz), "+v"(w.wlz) :: "memory");
+                                    lvox v[8];
+                                    v[0] = lds_at<lvox>(a0)[0]; v[1] = lds_at<lvox>(a0)[1]; v[2] = lds_at<lvox>(a1)[0]; v[3] = lds_at<lvox>(a1)[1];
+                                    v[4] = lds_at<lvox>(a2)[0]; v[5] = lds_at<lvox>(a2)[1]; v[6] = lds_at<lvox>(a3)[0]; v[7] = lds_at<lvox>(a3)[1];
+                                    f4 c[8];
 #pragma unroll
-                                for (int q = 0; q < 8; ++q) cvt_vox(v[q], c[q]);
-                                march_step_now(r, c, w, invx, invy, invz, win);
-                            }
+                                    for (int q = 0; q < 8; ++q) cvt_vox(v[q], c[q]);
+                                    march_step_now<kPrescaled, decltype(window_test)::value>(r, c, w, invx, invy, invz, win);
+                                }
+                            };
+                            if (win_all) proven(std::false_type{}); else proven(std::true_type{});
                             it -= Kg;
                         }
                         Kr -= (int)Kg;                   // whatever the plan allowed beyond the proof runs with the tests below
@@ -544,9 +591,9 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                             f4 c[8];
                             gather_lds(seg, mad24(mad24(cx, ey, cy), ez, cz), sy, sx, c);
                             if constexpr (kHasW) {
-                                if (march_step(r, c, invx, invy, invz, win, true)) { rem_w = it; it = 0; } else --it;
+                                if (march_step<kPrescaled>(r, c, invx, invy, invz, win, true)) { rem_w = it; it = 0; } else --it;
                             } else {
-                                (void)march_step(r, c, invx, invy, invz, win, false);
+                                (void)march_step<kPrescaled>(r, c, invx, invy, invz, win, false);
                                 --it;
                             }
                         }
@@ -664,19 +711,45 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
 #undef VRT_TL
 }
 
-template <typename FieldT, typename DirT, int VPL, int OCC, bool ABSORB>
-hipError_t launch_slab_vpl(const MarchParams &p, int num_cu, hipStream_t s)
+// ---- launch ----------------------------------------------------------------------------------------------------
+// The LDS segment per wavefront fixes the brick capacity, the wavefronts a CU holds (160 KiB LDS) and with them the
+// register budget.  Two sizes are complete (persistent and static schedule, absorption mode):
+//   10 KiB  640 voxels, 4 wavefronts / SIMD, 128 VGPRs   the default: longer rounds, fewer rounds that fit no brick
+//    6 KiB  384 voxels, 6 wavefronts / SIMD,  80 VGPRs   dense ray sets (more than kDenseRaysPerColumn rays per voxel column of the
+//                                                        largest face): tiles are narrow, bricks deep, occupancy wins
+// measured (kernel ms, 6 / 8 / 10 KiB): config 3 (4 rays per column) 8.58 / 8.41 / 8.32, config 4 (16 per column)
+// 25.9 / 26.8 / 26.9, config 5 (1 per column) 15.98 / 15.37 / 14.96.  The other sizes exist for vrt_options.slab_lds_bytes
+// (static schedule only).
+struct SlabGeometry { uint32_t seg_bytes; int occ; bool complete; };
+constexpr uint32_t kDenseRaysPerColumn = 8;
+inline SlabGeometry slab_geometry(uint32_t want, uint32_t nrays, uint32_t Bx, uint32_t By, uint32_t Bz)
 {
+    if (want == 0) {
+        const uint64_t bmax = Bx > By ? (Bx > Bz ? Bx : Bz) : (By > Bz ? By : Bz);
+        want = (uint64_t)nrays > (uint64_t)kDenseRaysPerColumn * bmax * bmax ? 6144u : 10240u;
+    }
+#ifdef VRT_SLAB_EXPERIMENT
+    const bool all = true;
+#else
+    const bool all = false;
+#endif
+    if (want <= 4096) return {4096, 8, all};
+    if (want <= 5120) return {5120, 7, all};
+    if (want <= 6144) return {6144, 6, true};
+    if (want <= 8192) return {8192, 5, all};
+    if (want <= 10240) return {10240, 4, true};
+    if (want <= 12288) return {12288, 3, all};
+    return {16384, 2, all};
+}
+
+template <typename FieldT, typename DirT, int BYTES, int OCC, bool ABSORB, bool COMPLETE>
+hipError_t launch_slab_bytes(const MarchParams &p, int num_cu, hipStream_t s)
+{
+    constexpr int VPL = BYTES / (64 * (int)sizeof(typename LdsVox<FieldT>::type));
     const unsigned threads = 64 * kSlabWavesPerBlock;
     const unsigned groups_blocks = (p.nrays + threads - 1) / threads;
-    const size_t lds = sizeof(typename LdsVox<FieldT>::type) * 64 * VPL * kSlabWavesPerBlock;
-    constexpr size_t seg_bytes = sizeof(typename LdsVox<FieldT>::type) * 64 * VPL;
-#ifdef VRT_SLAB_EXPERIMENT    // development builds: every segment size has the persistent variant (A/B of LDS sizes)
-    constexpr bool kHasPersist = true;
-#else
-    constexpr bool kHasPersist = seg_bytes == 6144 || seg_bytes == 8192;    // launch_slab sends persistent launches only here
-#endif
-    if constexpr (kHasPersist) if (p.group_counter) {
+    const size_t lds = (size_t)BYTES * kSlabWavesPerBlock;
+    if constexpr (COMPLETE) if (p.group_counter) {
         // persistent grid: the wavefronts the GPU holds at once (OCC per SIMD = OCC blocks of 4 wavefronts per CU)
         const unsigned resident = (unsigned)(num_cu > 0 ? num_cu : 256) * (unsigned)OCC;
         const unsigned grid = groups_blocks < resident ? groups_blocks : resident;
@@ -687,47 +760,27 @@ hipError_t launch_slab_vpl(const MarchParams &p, int num_cu, hipStream_t s)
     return hipGetLastError();
 }
 
-// slab_lds_bytes selects the LDS segment per wave (0 = default).  The voxel count per lane and the
-// register budget (waves per SIMD the allocator must allow) both follow from the byte size:
-// 160 KiB LDS / CU and 512 VGPRs per SIMD lane give 8 waves/SIMD at <= 5 KiB, 6 at 6 KiB, 5 at 8 KiB ...
-template <typename FieldT, typename DirT, int BYTES, int OCC, bool ABSORB = false>
-hipError_t launch_slab_bytes(const MarchParams &p, int num_cu, hipStream_t s)
-{
-    return launch_slab_vpl<FieldT, DirT, BYTES / (64 * (int)sizeof(typename LdsVox<FieldT>::type)), OCC, ABSORB>(p, num_cu, s);
-}
-
 template <typename FieldT, typename DirT>
-hipError_t launch_slab(MarchParams p, bool /*path*/, int num_cu, hipStream_t s)
+hipError_t launch_slab(const MarchParams &p, SlabGeometry g, int num_cu, hipStream_t s)
 {
-    // default: 6 KiB (24 waves/CU) measured best when the launch oversubscribes the GPU (configs 3, 4); a
-    // launch with fewer wavefronts than LDS slots loses nothing to a bigger segment and gains longer rounds,
-    // and so do sparse ray sets: at one ray per voxel column or fewer a 64-ray tile is >= 8 x 8 voxels wide,
-    // the 6 KiB brick is only a few voxels deep, and 8 KiB measured 5 % faster (config 5: 18.3 -> 17.4 ms;
-    // config 4 with 16 rays per column: 29.0 -> 32.1 ms, so dense sets stay at 6 KiB)
-    uint32_t want = p.slab_lds_bytes;
-    if (want == 0) {
-        const uint64_t waves_per_cu = ((uint64_t)p.nrays + 63) / 64 / (uint64_t)(num_cu > 0 ? num_cu : 256);
-        const uint64_t bmax = p.Bx > p.By ? (p.Bx > p.Bz ? p.Bx : p.Bz) : (p.By > p.Bz ? p.By : p.Bz);
-        const bool sparse = 2 * (uint64_t)p.nrays <= 3 * bmax * bmax;          // <= 1.5 rays per voxel of the largest face
-        want = (waves_per_cu <= 20 || sparse) ? 8192u : 6144u;
-    }
-    if (p.transl) {                                    // opt-in absorption mode: the two default sizes only
-        if (want <= 6144) return launch_slab_bytes<FieldT, DirT, 6144, 6, true>(p, num_cu, s);
-        return launch_slab_bytes<FieldT, DirT, 8192, 5, true>(p, num_cu, s);
-    }
-#ifndef VRT_SLAB_EXPERIMENT
-    if (p.group_counter || want == 6144 || want == 8192) { // the persistent variant exists for the two default sizes
-        if (want <= 6144) return launch_slab_bytes<FieldT, DirT, 6144, 6>(p, num_cu, s);
-        return launch_slab_bytes<FieldT, DirT, 8192, 5>(p, num_cu, s);
-    }
+#ifdef VRT_SLAB_EXPERIMENT
+    constexpr bool kAll = true;
+#else
+    constexpr bool kAll = false;
 #endif
-    if (want <= 4096) return launch_slab_bytes<FieldT, DirT, 4096, 8>(p, num_cu, s);
-    if (want <= 5120) return launch_slab_bytes<FieldT, DirT, 5120, 7>(p, num_cu, s);
-    if (want <= 6144) return launch_slab_bytes<FieldT, DirT, 6144, 6>(p, num_cu, s);
-    if (want <= 8192) return launch_slab_bytes<FieldT, DirT, 8192, 5>(p, num_cu, s);
-    if (want <= 10240) return launch_slab_bytes<FieldT, DirT, 10240, 4>(p, num_cu, s);
-    if (want <= 12288) return launch_slab_bytes<FieldT, DirT, 12288, 3>(p, num_cu, s);
-    return launch_slab_bytes<FieldT, DirT, 16384, 2>(p, num_cu, s);
+    if (p.transl) {                                    // opt-in absorption mode: the two complete sizes only
+        if (g.seg_bytes <= 6144) return launch_slab_bytes<FieldT, DirT, 6144, 6, true, true>(p, num_cu, s);
+        return launch_slab_bytes<FieldT, DirT, 10240, 4, true, true>(p, num_cu, s);
+    }
+    switch (g.seg_bytes) {
+    case 4096:  return launch_slab_bytes<FieldT, DirT, 4096, 8, false, kAll>(p, num_cu, s);
+    case 5120:  return launch_slab_bytes<FieldT, DirT, 5120, 7, false, kAll>(p, num_cu, s);
+    case 6144:  return launch_slab_bytes<FieldT, DirT, 6144, 6, false, true>(p, num_cu, s);
+    case 8192:  return launch_slab_bytes<FieldT, DirT, 8192, 5, false, kAll>(p, num_cu, s);
+    case 10240: return launch_slab_bytes<FieldT, DirT, 10240, 4, false, true>(p, num_cu, s);
+    case 12288: return launch_slab_bytes<FieldT, DirT, 12288, 3, false, kAll>(p, num_cu, s);
+    default:    return launch_slab_bytes<FieldT, DirT, 16384, 2, false, kAll>(p, num_cu, s);
+    }
 }
 
 }  // namespace vrt
