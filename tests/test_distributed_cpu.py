@@ -153,3 +153,21 @@ def test_balanced_bands():
     prof = np.concatenate([np.linspace(1, 10, 512), np.linspace(10, 1, 512)])
     b = D.balanced_bands(prof, 4)
     assert (b[0][1] - b[0][0]) > (b[1][1] - b[1][0]) and (b[3][1] - b[3][0]) > (b[2][1] - b[2][0])
+
+
+def test_strong_scaling_bands_tile_the_fixed_lattice():
+    """bench.py --scaling strong (BASELINE config 4: a FIXED R x R lattice cut into N row bands): the bands of ranks
+    0..N-1, concatenated in rank order, are exactly the rays of the single-GPU job, for every N the driver runs;
+    weak scaling instead grows the lattice to (R*N) x R with R rows per rank."""
+    import bench
+    cfg = dict(bench.CONFIGS[4], N=48, R=64)                       # config 4's shape at a size the CPU handles
+    sp1, sd1 = bench.make_rays(cfg, 0, 1, scaling="strong")
+    assert sp1.size // 3 == cfg["R"] ** 2
+    for world in (2, 4, 8):
+        assert bench.lattice_rows(cfg, world, "strong") == cfg["R"]
+        parts = [bench.make_rays(cfg, r, world, scaling="strong") for r in range(world)]
+        assert np.array_equal(np.concatenate([p[0] for p in parts]), sp1)
+        assert np.array_equal(np.concatenate([p[1] for p in parts]), sd1)
+        assert bench.lattice_rows(cfg, world, "weak") == cfg["R"] * world
+        w = [bench.make_rays(cfg, r, world, scaling="weak") for r in range(world)]
+        assert all(p[0].size // 3 == cfg["R"] ** 2 for p in w)

@@ -89,6 +89,31 @@ __device__ __forceinline__ uint32_t lane0_atomic_add(uint32_t *ptr, uint32_t v)
 }
 __device__ __forceinline__ uint64_t lane_mask(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 
+// ---- batched wave reductions -------------------------------------------------------------------------------------
+// The planner needs six to seven wave-wide minima / maxima per round.  One reduction is a chain of six dependent DPP
+// operations, each of which must wait two cycles for its source; the library reductions (__ockl_wfred_*) came out one
+// after the other, 36 dependent operations with their wait states -- most of the 5 000 cycles a planning round took
+// (tools/phases.py).  Here N reductions advance together, stage by stage: the same 6 N DPP operations, but every
+// stage's N instructions are independent and fill each other's wait states, and the chain is 6 long, not 6 N.
+// Unsigned minima: a maximum is taken as the minimum of the complement; signed values are biased by 2^31.
+// DPP controls (GFX9): row_shr:n = 0x110 + n, row_bcast:15 = 0x142, row_bcast:31 = 0x143; a lane without a source keeps
+// `old` = the identity 0xFFFFFFFF.  After row_shr 1, 2, 4, 8 lane 15 of each row of 16 holds its row's minimum;
+// row_bcast:15 (rows 1 and 3) and row_bcast:31 (rows 2 and 3) leave the wave's minimum in lane 63.
+template <int N>
+__device__ __forceinline__ void wave_min_u32(uint32_t (&v)[N])
+{
+#define VRT_DPP_STAGE(CTRL, ROWMASK)                                                                             \
+    _Pragma("unroll") for (int i = 0; i < N; ++i) {                                                             \
+        const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)v[i], CTRL, ROWMASK, 0xf, false); \
+        v[i] = t < v[i] ? t : v[i];                                                                             \
+    }
+    VRT_DPP_STAGE(0x111, 0xf) VRT_DPP_STAGE(0x112, 0xf) VRT_DPP_STAGE(0x114, 0xf) VRT_DPP_STAGE(0x118, 0xf)
+    VRT_DPP_STAGE(0x142, 0xa) VRT_DPP_STAGE(0x143, 0xc)
+#undef VRT_DPP_STAGE
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = (uint32_t)__builtin_amdgcn_readlane((int)v[i], 63);
+}
+
 // debug counters (MarchParams::stats != nullptr): per-wave events, added by lane 0
 enum { kStatRounds = 0, kStatPlannedK, kStatLdsWaveSteps, kStatDirectRounds, kStatDirectWaveSteps, kStatVoxStaged,
        kStatEarlyExit, kStatProvenRounds, kStatCount, kStatProvenSteps = 13 };
@@ -329,6 +354,7 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
     // march(): advances the wavefront's rays until all of them have stopped
     auto march = [&]() {
     uint32_t plan_round = 0;                            // wave-uniform
+    int last_rung = kSlabMaxK >> 3;                     // rung of the K ladder the previous round ended on (wave-uniform)
     int32_t sweep_neg[3] = {0, 0, 0}, sweep_pos[3] = {0, 0, 0};
     for (;;) {
         const bool live = it > 0 && in_field(r, bx1, by1, bz1);
@@ -351,10 +377,17 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                 s[1] = (int32_t)fminf(fmaxf((r.dy * invy) * ilen, -lim), lim);
                 s[2] = (int32_t)fminf(fmaxf((r.dz * invz) * ilen, -lim), lim);
             }
+            uint32_t red[6];                            // min(s_d) and max(s_d) as unsigned minima: bias by 2^31, complement for max
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-                const int32_t smn = (int32_t)sgpr((uint32_t)__ockl_wfred_min_i32(live ? s[d] : 0x7FFFFFFF));
-                const int32_t smx = (int32_t)sgpr((uint32_t)__ockl_wfred_max_i32(live ? s[d] : (int32_t)0x80000000));
+                red[2 * d] = live ? (uint32_t)s[d] ^ 0x80000000u : 0xFFFFFFFFu;
+                red[2 * d + 1] = live ? ~((uint32_t)s[d] ^ 0x80000000u) : 0xFFFFFFFFu;
+            }
+            wave_min_u32(red);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int32_t smn = (int32_t)(red[2 * d] ^ 0x80000000u);
+                const int32_t smx = (int32_t)(~red[2 * d + 1] ^ 0x80000000u);
                 int32_t a = smn >> 8, c = (smx >> 8) + 1;          // floor / ceil (+1 keeps it conservative)
                 a = a > 0 ? 0 : (a < -(1 << 20) ? -(1 << 20) : a);
                 c = c < 0 ? 0 : (c > (1 << 20) ? (1 << 20) : c);
@@ -364,23 +397,44 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
         }
         {
             const uint32_t px[3] = {r.px, r.py, r.pz};
+            uint32_t red[6];
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-                const uint32_t lo = sgpr(__ockl_wfred_min_u32(live ? px[d] : 0xFFFFFFFFu));
-                const uint32_t hi = sgpr(__ockl_wfred_max_u32(live ? px[d] : 0u));
+                red[2 * d] = live ? px[d] : 0xFFFFFFFFu;
+                red[2 * d + 1] = live ? ~px[d] : 0xFFFFFFFFu;
+            }
+            wave_min_u32(red);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const uint32_t lo = red[2 * d];
+                const uint32_t hi = ~red[2 * d + 1];
                 in.pmin8[d] = (int32_t)(lo >> 8);
                 in.pmax8[d] = (int32_t)((hi >> 8) + 1);
                 in.sneg8[d] = sweep_neg[d];
                 in.spos8[d] = sweep_pos[d];
             }
         }
+        // largest K of the ladder kSlabMaxK, /2, /4 ... 1 whose brick fits (the volume grows with K).  The search starts
+        // at the rung the previous round of this group ended on -- it rarely moves by more than one -- and walks up or
+        // down from there: the same K as a search from the top, in two or three evaluations instead of four or five.
         Brick bk;
-        int K = kSlabMaxK;
+        int K = last_rung;
         uint32_t vol = plan_brick(in, K, B, kCap, bk);
-        while (vol > kCap && K > 1) {
-            K >>= 1;
-            vol = plan_brick(in, K, B, kCap, bk);
+        if (vol <= kCap) {
+            while (K < kSlabMaxK) {
+                Brick b2;
+                const int Kn = (K << 1) > kSlabMaxK ? kSlabMaxK : (K << 1);
+                const uint32_t v2 = plan_brick(in, Kn, B, kCap, b2);
+                if (v2 > kCap) break;
+                K = Kn; vol = v2; bk = b2;
+            }
+        } else {
+            while (vol > kCap && K > 1) {
+                K >>= 1;
+                vol = plan_brick(in, K, B, kCap, bk);
+            }
         }
+        last_rung = K;
         if (vol <= kCap && K >= 2 && K < kSlabMaxK) {   // the halving search is coarse: try 1.5 K
             Brick b2;
             const int K2 = K + (K >> 1);
@@ -515,9 +569,12 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                 const bool pos0 = live;
                 int Kr = Ku;
                 if constexpr (!kDies) {
-                    const uint32_t min_it = sgpr(__ockl_wfred_min_u32(pos0 ? it : 0xFFFFFFFFu));
+#ifdef VRT_SLAB_NO_PROOF
+                    uint32_t red1[1] = {pos0 ? it : 0xFFFFFFFFu};
+                    wave_min_u32(red1);
+                    const uint32_t min_it = red1[0];
                     Kr = (uint32_t)Ku < min_it ? Ku : (int)min_it;
-#ifndef VRT_SLAB_NO_PROOF
+#else
                     // proven part of the round: no lane can leave the brick during Kg steps (safe_steps), so the loop
                     // carries no brick test, no ballot and no exit -- lanes not live at the start of the round stay masked
                     bool win_mine = true;
@@ -525,7 +582,11 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                                                              (ex1 << 16) - 1u, (ey1 << 16) - 1u, (ez1 << 16) - 1u, win, win_mine)
                                                : 0xFFFFFFFFu;
                     const bool win_all = !any_lane(pos0 && !win_mine);
-                    uint32_t Kg = sgpr(__ockl_wfred_min_u32(mine));
+                    uint32_t red2[2] = {pos0 ? it : 0xFFFFFFFFu, mine};
+                    wave_min_u32(red2);                    // smallest remaining iteration count, smallest proven run
+                    const uint32_t min_it = red2[0];
+                    Kr = (uint32_t)Ku < min_it ? Ku : (int)min_it;
+                    uint32_t Kg = red2[1];
                     Kg = Kg < (uint32_t)Kr ? Kg : (uint32_t)Kr;
                     if (Kg >= (uint32_t)kSlabMinSafe) {
                         stat_add(p, kStatProvenRounds, 1);
