@@ -263,8 +263,9 @@ def device_copy_gbs(dev, nbytes=1 << 30, reps=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=5,
+                    help="untimed steps; the engine settles its schedule choice for the workload during the first four calls")
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
     ap.add_argument("--kernel", default="auto", choices=["auto", "direct", "slab"])
     ap.add_argument("--schedule", type=int, default=0, help="slab kernel scheduling: 0 auto, 1 static, 2 persistent wavefronts")

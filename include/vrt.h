@@ -68,7 +68,9 @@ typedef struct vrt_options {
                               * translucency resident) AND at vrt_trace.  PARITY UNPINNED: no reference build
                               * can execute this branch; the checker is oracle/vrt_oracle.c's restatement. */
     int32_t  schedule;       /* extension: slab-kernel scheduling. 0 = auto, 1 = static (one wavefront per group of 64
-                                rays, hardware dispatch order), 2 = persistent wavefronts drawing groups from a counter */
+                                rays, hardware dispatch order), 2 = persistent wavefronts drawing groups from a counter,
+                                3 = persistent and time-sliced (a group marches 1024 wave-steps, parks its ray state and is
+                                resumed by whichever wavefront draws its next ticket; all groups advance and end together) */
     int32_t  devices;        /* extension, read at vrt_create: bit mask of HIP device ordinals the handle spans (bit d = device d),
                               * 0 = only `device` (default), -1 = every visible device.  The field is replicated on each of
                               * them, as the reference's constructor does (cuda_volume_raytracer.cu:676-686), and the
@@ -76,7 +78,8 @@ typedef struct vrt_options {
                               * the reference spreads its chunks over all devices (.cu:804-912).  Device-pointer calls use
                               * the primary device (`device`, or the lowest bit of the mask when device = -1). */
     int32_t  host_lanes;     /* extension: chunks a host-pointer call is cut into per device (pipelined over up to 4 streams so
-                              * that uploads and downloads overlap the march), 0 = auto (4 above 2^19 rays, 2 above 2^17, else 1) */
+                              * that uploads and downloads overlap the march), 0 = auto = 1 (measured best: every chunk pays
+                              * its own ray ordering and launch tail) */
 } vrt_options;
 
 #define VRT_KERNEL_AUTO   0

@@ -172,3 +172,39 @@ def test_march_clock_is_reported():
         ghz = eng.last_march_clock_ghz()
         assert 0.3 < ghz < 3.0, ghz
         assert np.array_equal(o[2].cpu().numpy().view(np.uint32), want["end_iteration"])
+
+
+def test_schedule_auto_tuning_keeps_results():
+    """vrt_options.schedule = 0 on a launch larger than the GPU holds: the engine alternates the whole-group and the
+    time-sliced persistent schedule over its first calls, times them with HIP events and keeps the faster
+    (vrt_engine.hip, Workspace::Tuner).  Every call along the way -- trials, undecided, decided -- gives the same bits;
+    a change of the ray count starts a new trial series."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    N = 72
+    bounds, dx, dy, dz, tc = W.seam_field(N, np.float32, seed=3)
+    sp, sd = W.perspective_rays(N, 640)                       # 409 600 rays = 6400 groups > 4096 resident wavefronts
+    field = oracle.port.interleave(dx, dy, dz, tc)
+    idx = np.linspace(0, sp.size // 3 - 1, 4000).astype(np.int64)
+    want = oracle.port.trace(field, bounds, sp.reshape(-1, 3)[idx].reshape(-1), sd.reshape(-1, 3)[idx].reshape(-1), [1, 1, 1], 100000)
+    n = sp.size // 3
+    with capi.Engine.from_host(bounds, [dx, dy, dz], tc) as eng:
+        t_sp = torch.from_numpy(sp.view(np.int32)).to(dev)
+        t_sd = torch.from_numpy(sd).to(dev)
+        first = None
+        for call in range(9):
+            m = n if call < 7 else n - 64 * 100                # calls 7, 8: another shape -> another trial series
+            o = [torch.zeros(3 * m, dtype=torch.int32, device=dev), torch.zeros(3 * m, dtype=torch.float32, device=dev),
+                 torch.zeros(m, dtype=torch.int32, device=dev), torch.zeros(m, dtype=torch.int32, device=dev)]
+            eng.trace_device(capi.VRT_F32, m, t_sp.data_ptr(), t_sd.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(),
+                             o[3].data_ptr(), [1, 1, 1], 100000)
+            torch.cuda.synchronize()
+            got = [x.cpu().numpy() for x in o]
+            if first is None:
+                first = got
+                assert np.array_equal(got[0].view(np.uint32).reshape(-1, 3)[idx], want["end_position"].reshape(-1, 3))
+                assert np.array_equal(got[1].view(np.uint32).reshape(-1, 3)[idx], want["end_direction"].view(np.uint32).reshape(-1, 3))
+                assert np.array_equal(got[2].view(np.uint32)[idx], want["end_iteration"])
+            else:
+                for a, b in zip(got, first):
+                    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)[:a.size]), "call %d" % call

@@ -335,6 +335,37 @@ def test_persistent_schedule(fdt, ddt):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fdt,ddt", [(np.float32, np.float32), (np.int16, np.int16)])
+@pytest.mark.parametrize("slice_steps", [16, 100, 1024])
+def test_time_sliced_schedule(fdt, ddt, slice_steps, monkeypatch):
+    """schedule = 3: persistent wavefronts draw (slice, group) tickets; a group marches `slice_steps` wave-steps, parks
+    its ray state in global memory (write-through stores, flag, vrt_slab.h) and is resumed by whichever wavefront
+    draws its next ticket.  Slices far shorter than the rays' lives (16 steps: a few hundred hand-offs per group) and
+    the production length must both reproduce the oracle bit for bit, with rays stopped by opacity, by the field
+    boundary and by a tight iteration cap, NaN / inf / zero directions and a launch order by caller / tile / longest
+    first."""
+    monkeypatch.setenv("VRT_SLICE_STEPS", str(slice_steps))
+    N = 40
+    bounds, dx, dy, dz, tc = W.seam_field(N, fdt, opaque_radius=5.0)
+    field = oracle.port.interleave(dx, dy, dz, tc)
+    sp1, sd1 = W.perspective_rays(N, 75, dir_dtype=ddt)
+    sp2, sd2 = W.random_rays(N, 3001, seed=5, vol_seed=1234)
+    if ddt == np.int16:
+        sd2 = np.clip(np.round(sd2 * 256.0), -32768, 32767).astype(np.int16)
+    sp, sd = np.concatenate([sp1, sp2]), np.concatenate([sd1, sd2])
+    if ddt == np.float32:
+        sd.reshape(-1, 3)[5::173, 1] = np.nan
+        sd.reshape(-1, 3)[7::191, 0] = np.inf
+        sd.reshape(-1, 3)[11::197] = 0.0
+    for inv, cap in (([1, 1, 1], 100000), ([0.5, 1, 2], 300)):
+        want = oracle.port.trace(field, bounds, sp, sd, inv, cap)
+        with capi.Engine.from_host(bounds, [dx, dy, dz], tc) as eng:
+            for sort in (-1, 1, 3):
+                got = eng.trace(sp, sd, inv, cap, options=_opts(capi.KERNEL_SLAB, sort, schedule=3))
+                _assert_same(got, want, ctx="slice=%d inv=%s cap=%d sort=%d" % (slice_steps, inv, cap, sort))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 129, 257])
 def test_tiny_launches_with_forced_order_and_schedule(n):
     """Ray counts around the wavefront size with every launch-order / schedule feature forced on: one group
@@ -346,7 +377,7 @@ def test_tiny_launches_with_forced_order_and_schedule(n):
     want = oracle.port.trace(field, bounds, sp, sd, [1, 1, 1], 5000)
     with capi.Engine.from_host(bounds, [dx, dy, dz], tc) as eng:
         for sort in (-1, 1, 2, 3):
-            for schedule in (1, 2):
+            for schedule in (1, 2, 3):
                 got = eng.trace(sp, sd, [1, 1, 1], 5000, options=_opts(capi.KERNEL_SLAB, sort, schedule=schedule))
                 _assert_same(got, want, ctx="n=%d sort=%d schedule=%d" % (n, sort, schedule))
 

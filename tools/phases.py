@@ -54,6 +54,9 @@ def main():
           % (lds, dr, 100 * dr / max(lds + dr, 1), rounds, lds / max(rounds, 1)))
     print("wall cycles per wave-step: lds %.0f  global %.0f;  per round: plan %.0f stage %.0f" %
           (ph[2] / max(lds, 1), ph[3] / max(dr, 1), ph[0] / max(rounds, 1), ph[1] / max(rounds, 1)))
+    print("scheduler words: tickets %d, groups finished %d, error %d" % (raw[60], raw[61], raw[62]))
+    if raw[30] > 0:
+        print("time-sliced schedule: tickets %d (wasted on finished groups %d), tickets that had to wait %d, polls %d" % (raw[30], raw[31], raw[33], raw[32]))
     simd_cycles = ms * 1e-3 * clock * eng_simds()
     print("SIMD-cycles of the launch per wave-step: %.0f (1024 SIMDs x kernel time x clock / wave-steps)" % (simd_cycles / (lds + dr)))
 

@@ -215,10 +215,11 @@ class Engine:
 
     def debug_stats(self):
         """Slab-kernel debug counters of the last launch (needs VRT_DEBUG_STATS=1)."""
-        buf = (C.c_ulonglong * 16)()
-        check(load().vrt_engine_debug_stats(self._h, buf, 16))
+        buf = (C.c_ulonglong * 18)()
+        check(load().vrt_engine_debug_stats(self._h, buf, 18))
         names = ("rounds", "planned_K_sum", "lds_wave_steps", "direct_rounds", "direct_wave_steps", "vox_staged",
-                 "early_exit", "proven_rounds", "fb_ex_sum", "fb_ey_sum", "fb_ez_sum", "fb_live_lanes_sum", "fb_steps_done_sum", "proven_steps")
+                 "early_exit", "proven_rounds", "fb_ex_sum", "fb_ey_sum", "fb_ez_sum", "fb_live_lanes_sum", "fb_steps_done_sum", "proven_steps", "fb_fit2_K8", "fb_fit4_K8",
+                 "fb_fit2_K16", "fb_fit4_K16")
         return dict(zip(names, [int(x) for x in buf]))
 
     def last_march_ms(self):

@@ -77,6 +77,16 @@ struct DevBuf {
         if (e == hipSuccess) cap = bytes;
         return e;
     }
+    // device memory the L2s do not cache (MTYPE UC): for the few words and parked ray states that wavefronts on different
+    // XCDs hand to each other inside one launch
+    hipError_t reserve_uncached(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
@@ -114,16 +124,30 @@ struct Workspace {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;   // around the most recent march kernel of this lane
     hipEvent_t ev_done = nullptr;                      // after the last launch that used these buffers
     bool ev_valid = false, used = false;
+    bool last_sliced = false;                          // the lane's most recent march used the time-sliced schedule
+    // Schedule auto-tuning (vrt_options.schedule = 0): whether time slicing pays depends on how unevenly the groups of a
+    // launch run, which is not known beforehand (config 5: 14.7 -> 13.7 ms; a 1448 x 1448 lattice on 512^3: 13.8 -> 15.5).
+    // The first launches of a workload shape alternate between the whole-group and the time-sliced schedule, HIP events
+    // around each; once the second pair has finished (hipEventQuery, never a wait) the faster one is kept for that shape.
+    struct Tuner {
+        unsigned long long key = 0;
+        int state = 0;                                 // 0..3: trial launches (2, 3, 2, 3); 4: waiting for the events; 5: decided
+        int choice = 2;
+        hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [schedule 2 | 3][begin | end] of the second trial pair
+        float ms[2] = {0.0f, 0.0f};
+    } tuner;
     DevBuf sort_keys, sort_keys_alt, sort_vals, sort_vals_alt, sort_tmp, sort_bounds;
     DevBuf group_ctr;              // group counter of the persistent slab kernel (vrt_options.schedule)
+    DevBuf park, slice_flags;      // time-sliced schedule: parked ray state (2 KiB per group) and per-group slice flags
     DevBuf clock;                  // (s_memtime, s_memrealtime) at the start and end of one wavefront of the march
     DevBuf stats;                  // debug counters, allocated only when VRT_DEBUG_STATS=1
     size_t stats_count = 0;
     DevBuf in_pos, in_dir, out_pos, out_dir, out_iter, out_light, path;   // device staging of host-pointer calls
     DevBuf pro_pos, pro_dir, err;  // scene layer: prologue outputs of device-pointer calls, error words
     void *pin_err = nullptr;       // pinned host copy of the error words (scene layer)
-    DevBuf *all[18] = {&sort_keys, &sort_keys_alt, &sort_vals, &sort_vals_alt, &sort_tmp, &sort_bounds, &group_ctr, &clock,
-                       &stats, &in_pos, &in_dir, &out_pos, &out_dir, &out_iter, &out_light, &path, &pro_pos, &pro_dir};
+    DevBuf *all[20] = {&sort_keys, &sort_keys_alt, &sort_vals, &sort_vals_alt, &sort_tmp, &sort_bounds, &group_ctr, &clock,
+                       &stats, &in_pos, &in_dir, &out_pos, &out_dir, &out_iter, &out_light, &path, &pro_pos, &pro_dir,
+                       &park, &slice_flags};
 };
 constexpr int kLanes = 4;
 
@@ -289,7 +313,8 @@ int workspace_init(Workspace &w)
 void workspace_free(Workspace &w)
 {
     if (w.stream) { (void)hipStreamSynchronize(w.stream); (void)hipStreamDestroy(w.stream); }
-    for (hipEvent_t ev : {w.ev_begin, w.ev_end, w.ev_done}) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : {w.ev_begin, w.ev_end, w.ev_done, w.tuner.ev[0][0], w.tuner.ev[0][1], w.tuner.ev[1][0], w.tuner.ev[1][1]})
+        if (ev) (void)hipEventDestroy(ev);
     for (DevBuf *b : w.all) b->release();
     w.err.release();
     if (w.pin_err) (void)hipHostFree(w.pin_err);
@@ -452,17 +477,68 @@ int trace_device_impl(vrt_engine *e, Workspace &w, int dir_type, size_t nrays, c
     // scheduling of the slab kernel: static (one wavefront per group of 64 rays, hardware dispatch) or
     // persistent (as many wavefronts as the GPU holds, each drawing groups from a counter)
     p.group_counter = nullptr;
+    int tuner_trial = -1;
     {
         const size_t groups = (nrays + 63) / 64;
         int schedule = o.schedule;
         if (const char *ev = getenv("VRT_SCHEDULE"); ev && schedule == 0) schedule = atoi(ev);
-        if (schedule < 0 || schedule > 2) return fail(VRT_ERR_INVALID_ARGUMENT, "unknown schedule %d", schedule);
-        // auto: persistent once the launch has more wavefronts than the GPU holds (measured -4 % on config 3)
-        if (schedule == 0) schedule = groups > resident_waves ? 2 : 1;
-        if (schedule == 2 && kernel == VRT_KERNEL_SLAB && groups > 1 && geo.complete) {
-            HIP_TRY(w.group_ctr.reserve(sizeof(uint32_t)));
-            HIP_TRY(hipMemsetAsync(w.group_ctr.p, 0, sizeof(uint32_t), s));
+        if (schedule < 0 || schedule > 3) return fail(VRT_ERR_INVALID_ARGUMENT, "unknown schedule %d", schedule);
+        // auto: persistent once the launch has more wavefronts than the GPU holds (measured -4 % on config 3); whether the
+        // persistent wavefronts take whole groups (2) or time slices (3) is settled by measurement (Workspace::Tuner)
+        int trial = -1;                                  // 0 / 1: this launch is the timed trial of schedule 2 / 3
+        if (schedule == 0) {
+            schedule = groups > resident_waves ? 2 : 1;
+            if (schedule == 2 && kernel == VRT_KERNEL_SLAB && geo.complete && !p.transl) {
+                Workspace::Tuner &t = w.tuner;
+                unsigned long long key = 1469598103934665603ull;
+                auto mix = [&key](unsigned long long v) { key = (key ^ v) * 1099511628211ull; };
+                mix(nrays); mix(iterations); mix((unsigned long long)dir_type); mix(geo.seg_bytes); mix((unsigned long long)o.sort_rays);
+                for (int d = 0; d < 3; ++d) { uint32_t b; memcpy(&b, &invscale[d], 4); mix(b); }
+                if (t.key != key) { t.key = key; t.state = 0; t.choice = 2; }
+                if (t.state < 4) {
+                    schedule = (t.state & 1) ? 3 : 2;
+                    if (t.state >= 2) {
+                        trial = t.state & 1;
+                        for (int k = 0; k < 2; ++k) if (!t.ev[trial][k]) HIP_TRY(hipEventCreate(&t.ev[trial][k]));
+                    }
+                    ++t.state;
+                } else if (t.state == 4) {
+                    schedule = 2;
+                    if (hipEventQuery(t.ev[0][1]) == hipSuccess && hipEventQuery(t.ev[1][1]) == hipSuccess &&
+                        hipEventElapsedTime(&t.ms[0], t.ev[0][0], t.ev[0][1]) == hipSuccess &&
+                        hipEventElapsedTime(&t.ms[1], t.ev[1][0], t.ev[1][1]) == hipSuccess) {
+                        t.choice = t.ms[1] < 0.98f * t.ms[0] ? 3 : 2;
+                        t.state = 5;
+                        schedule = t.choice;
+                        if (o.loglevel < 0) printf("schedule tuned: whole groups %.3f ms, time-sliced %.3f ms -> %d\n", t.ms[0], t.ms[1], t.choice);
+                    }
+                    (void)hipGetLastError();                 // hipErrorNotReady from the queries is not an error
+                } else {
+                    schedule = t.choice;
+                }
+            }
+        }
+        p.park = nullptr; p.slice_flags = nullptr; p.slice_steps = 0; p.ticket_limit = 0;
+        if (schedule >= 2 && kernel == VRT_KERNEL_SLAB && groups > 1 && geo.complete) {
+            HIP_TRY(w.group_ctr.reserve(4 * sizeof(uint32_t)));
+            HIP_TRY(hipMemsetAsync(w.group_ctr.p, 0, 4 * sizeof(uint32_t), s));
             p.group_counter = (uint32_t *)w.group_ctr.p;
+            tuner_trial = trial;
+            if (schedule == 3 && !p.transl) {
+                // time-sliced: parked state and per-group slice flags (vrt_slab.h, SCHED == 2)
+                uint32_t slice = 1024;
+                if (const char *ev = getenv("VRT_SLICE_STEPS")) slice = (uint32_t)std::max(16L, strtol(ev, nullptr, 10));
+                // ring of re-queued groups: a power of two >= 2 x groups (at most one word per group is ever occupied)
+                unsigned long long cap = 64;
+                while (cap < 2ull * groups) cap <<= 1;
+                HIP_TRY(w.park.reserve_uncached(groups * 2048));
+                HIP_TRY(w.slice_flags.reserve_uncached((size_t)cap * sizeof(uint32_t)));
+                HIP_TRY(hipMemsetAsync(w.slice_flags.p, 0, (size_t)cap * sizeof(uint32_t), s));
+                p.park = w.park.p;
+                p.slice_flags = (uint32_t *)w.slice_flags.p;
+                p.slice_steps = slice;
+                p.ticket_limit = (uint32_t)cap;
+            }
         }
     }
 
@@ -474,16 +550,19 @@ int trace_device_impl(vrt_engine *e, Workspace &w, int dir_type, size_t nrays, c
 
     Range range("vrt: march");
     HIP_TRY(hipEventRecord(w.ev_begin, s));
+    if (tuner_trial >= 0) HIP_TRY(hipEventRecord(w.tuner.ev[tuner_trial][0], s));
     int rc;
     if (e->field_type == VRT_F32)
         rc = dir_type == VRT_F32 ? launch_typed<float, float>(e, p, kernel, geo, s) : launch_typed<float, int16_t>(e, p, kernel, geo, s);
     else
         rc = dir_type == VRT_F32 ? launch_typed<int16_t, float>(e, p, kernel, geo, s) : launch_typed<int16_t, int16_t>(e, p, kernel, geo, s);
     if (rc) return rc;
+    if (tuner_trial >= 0) HIP_TRY(hipEventRecord(w.tuner.ev[tuner_trial][1], s));
     HIP_TRY(hipEventRecord(w.ev_end, s));
     HIP_TRY(hipEventRecord(w.ev_done, s));
     w.ev_valid = true;
     w.used = true;
+    w.last_sliced = p.park != nullptr;
     return VRT_OK;
 }
 
@@ -561,6 +640,13 @@ int trace_host_chunk(vrt_engine *e, Workspace &w, const HostCall &c, size_t off,
                                    hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
     }
+    if (w.last_sliced) {
+        // the time-sliced schedule bounds every wait and raises its error word instead of hanging (vrt_slab.h); a
+        // raised word means rays were left unfinished -- it has never been observed, and must not pass silently
+        uint32_t words[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpy(words, w.group_ctr.p, sizeof words, hipMemcpyDeviceToHost));
+        if (words[2] != 0) return fail(VRT_ERR_HIP, "time-sliced schedule: a wavefront gave up waiting (%u); results are incomplete", words[2]);
+    }
     return hooks.post(e, w, n, off);
 }
 
@@ -578,13 +664,17 @@ void band_cut(size_t n, size_t parts, std::vector<size_t> &begin)
     begin[parts] = n;
 }
 
-// chunks per device for the lane pipeline: enough to hide the copies, few enough to keep every launch large
+// chunks per device for the lane pipeline
 size_t host_chunks(const vrt_options &o, size_t nrays, bool path)
 {
     if (path) return 1;                                  // path tracing is chunked by the device path budget instead
     int want = o.host_lanes;
     if (const char *ev = getenv("VRT_HOST_LANES"); ev && want == 0) want = atoi(ev);
-    if (want <= 0) want = nrays >= ((size_t)1 << 19) ? 4 : (nrays >= ((size_t)1 << 17) ? 2 : 1);
+    // auto = one chunk.  Measured on BASELINE config 3 (tools/host_path.py, 10^6 rays, 24 MB up + 32 MB down from pageable
+    // memory): 1 chunk 10.5 ms, 2 chunks 10.7, 4 chunks 13.4, 8 chunks 15.7 against 8.9 ms for the device-resident call --
+    // every chunk pays its own ray ordering and its own launch tail, and concurrent marches share one GPU, which costs
+    // more than the 1.6 ms of copies a pipeline can hide.  The knob stays for callers whose copies dominate.
+    if (want <= 0) want = 1;
     return (size_t)std::min(want, 64);
 }
 
@@ -1208,6 +1298,11 @@ int vrt_engine_debug_stats(vrt_handle h, unsigned long long *out, int n)
     DeviceGuard g(h->device);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, w.stats.p, sizeof(unsigned long long) * std::min((size_t)n, w.stats_count), hipMemcpyDeviceToHost));
+    if (n >= 64 && w.group_ctr.p) {                        // scheduler words of the last launch: tickets, groups finished, error
+        uint32_t c[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpy(c, w.group_ctr.p, std::min<size_t>(sizeof c, w.group_ctr.cap), hipMemcpyDeviceToHost));
+        for (int k = 0; k < 4; ++k) out[60 + k] = c[k];
+    }
     return VRT_OK;
 }
 

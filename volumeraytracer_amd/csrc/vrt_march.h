@@ -38,7 +38,12 @@ struct MarchParams {
     unsigned long long *stats; // optional debug counters (nullptr in production), see vrt_slab.h
     const uint32_t *transl;   // ABSORB kernels only: translucency per field voxel (opt-in mode, .cu:337-341)
     uint32_t min_brightness;  // ABSORB kernels only
-    uint32_t *group_counter;  // persistent slab kernel only: next group of 64 slots to start (zeroed per launch)
+    uint32_t *group_counter;  // persistent slab kernel only: next group of 64 slots to start (zeroed per launch);
+                              // time-sliced schedule: [0] items drawn, [1] groups finished, [2] error word, [3] items appended
+    void *park;               // time-sliced schedule only: parked ray state, 2 KiB per group ([group][2][64 lanes] x 16 B)
+    uint32_t *slice_flags;    // time-sliced schedule only: the FIFO of re-queued groups (group + 1; 0 = not written yet)
+    uint32_t slice_steps;     // time-sliced schedule only: wave-steps per slice
+    uint32_t ticket_limit;    // time-sliced schedule only: words in the FIFO ring (a power of two >= 2 x groups)
     uint32_t out_pos_bias;    // added to end_pos / path on output: 0 at the seam, 0x10000 for the scene
                               // layer's "+0x10000" epilogue (image_util.cpp:770-771)
     unsigned long long *clock_out; // optional: 4 words {s_memtime, s_memrealtime} x {begin, end} of one wavefront (wave 0 of block 0)

@@ -88,6 +88,37 @@ __device__ __forceinline__ uint32_t lane0_atomic_add(uint32_t *ptr, uint32_t v)
     return __builtin_amdgcn_readfirstlane(old);
 }
 __device__ __forceinline__ uint64_t lane_mask(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+// compare-and-swap by lane 0 (same EXEC narrowing): *ptr = (*ptr == expect) ? value : *ptr; returns the old word
+__device__ __forceinline__ uint32_t lane0_atomic_cas(uint32_t *ptr, uint32_t expect, uint32_t value)
+{
+    uint32_t old;
+    unsigned long long saved;
+    const unsigned long long pair = ((unsigned long long)expect << 32) | value;      // {data, compare} in consecutive registers
+    asm volatile("s_mov_b64 %1, exec\n\t"
+                 "s_mov_b64 exec, 1\n\t"
+                 "global_atomic_cmpswap %0, %2, %3, off sc0\n\t"
+                 "s_waitcnt vmcnt(0)\n\t"
+                 "s_mov_b64 exec, %1"
+                 : "=&v"(old), "=&s"(saved) : "v"(ptr), "v"(pair) : "memory");
+    return __builtin_amdgcn_readfirstlane(old);
+}
+
+// ---- hand-off primitives of the time-sliced schedule (SCHED == 2) -------------------------------------------------
+// A group's ray state travels between wavefronts that may sit on different XCDs, whose L2s are not coherent with each
+// other.  The parked bytes live in uncached device memory (hipDeviceMallocUncached) and are moved with write-through
+// (sc1) stores and sc1 loads; the storing wave drains them (s_waitcnt vmcnt(0)) before lane 0 moves the group's flag,
+// and flags / counters are touched by device-scope atomics only -- no cache-wide fences (they cost microseconds each).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_sc1_b128(void *ptr, u32x4 v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(ptr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void load_sc1_2xb128(const void *p0, const void *p1, u32x4 &v0, u32x4 &v1)   // both in flight, one wait
+{
+    asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %1, %3, off sc0 sc1\n\t"
+                 "s_waitcnt vmcnt(0)" : "=&v"(v0), "=&v"(v1) : "v"(p0), "v"(p1) : "memory");
+}
 
 // ---- batched wave reductions -------------------------------------------------------------------------------------
 // The planner needs six to seven wave-wide minima / maxima per round.  One reduction is a chain of six dependent DPP
@@ -312,9 +343,14 @@ __device__ __forceinline__ void gather_lds(const LV *seg, uint32_t base, uint32_
 
 // VPL = voxels staged per lane at most; the wave's LDS segment holds 64*VPL fp32 voxels (16 B each).
 // OCC = waves per SIMD the register allocator must allow (launch-bounds second argument).
-template <typename FieldT, typename DirT, int VPL, int OCC, bool ABSORB, bool PERSIST = false>
+// SCHED: 0 static (one wavefront per group of 64 slots), 1 persistent (wavefronts draw whole groups from a counter),
+// 2 persistent and time-sliced (wavefronts draw (slice, group) tickets: a group marches slice_steps wave-steps, parks its
+// ray state in global memory and is resumed later by whichever wavefront draws its next ticket).
+template <typename FieldT, typename DirT, int VPL, int OCC, bool ABSORB, int SCHED = 0>
 __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(const MarchParams p)
 {
+    constexpr bool PERSIST = SCHED != 0;
+    constexpr bool SLICED = SCHED == 2;
     using vox = typename FieldTraits<FieldT>::vox;
     constexpr uint32_t kCap = 64u * VPL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -349,9 +385,14 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
     const unsigned long long ph_t0 = ph_stamp(), ph_r0 = ph_realtime();
     unsigned long long ph_t = ph_t0;
     unsigned long long tl_lds_total = 0, tl_dir_total = 0, tl_rounds_total = 0;
+    uint32_t sl_tickets = 0, sl_wasted = 0, sl_polls = 0, sl_waits = 0;
+#define VRT_SL(x) (x)
+#else
+#define VRT_SL(x) ((void)0)
 #endif
 
     // march(): advances the wavefront's rays until all of them have stopped
+    uint32_t budget = 0xFFFFFFFFu;                      // wave-steps the current slice may still run (SLICED; wave-uniform)
     auto march = [&]() {
     uint32_t plan_round = 0;                            // wave-uniform
     int last_rung = kSlabMaxK >> 3;                     // rung of the K ladder the previous round ended on (wave-uniform)
@@ -360,6 +401,7 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
         const bool live = it > 0 && in_field(r, bx1, by1, bz1);
         VRT_PH(kPhOther);
         if (!any_lane(live)) return;             // wave early-out: every lane has terminated
+        if constexpr (SLICED) { if (budget == 0u) return; }      // slice used up: the caller parks the group
 
         // ---- plan -------------------------------------------------------------------------
         // A wave reduction costs about 50 cycles (five DPP stages with their hazard slots, two readlanes), twelve
@@ -500,6 +542,35 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
             stat_add(p, 8, bk.e[0]); stat_add(p, 9, bk.e[1]); stat_add(p, 10, bk.e[2]);      // fallback brick extents (K = 1)
             stat_add(p, 11, (unsigned long long)__popcll(__ballot(live)));                    // live lanes at fallback
             stat_add(p, 12, (unsigned long long)(p.iterations - 1 - sgpr(__ockl_wfred_max_u32(live ? it : 0u))));  // steps done (min over lanes)
+            {   // would the live lanes fit TWO (or four) bricks?  split at the middle of the widest (two widest) bounding-box axes
+                int ext[3] = {in.pmax8[0] - in.pmin8[0], in.pmax8[1] - in.pmin8[1], in.pmax8[2] - in.pmin8[2]};
+                int a0 = ext[0] >= ext[1] ? (ext[0] >= ext[2] ? 0 : 2) : (ext[1] >= ext[2] ? 1 : 2);
+                int a1 = a0 == 0 ? (ext[1] >= ext[2] ? 1 : 2) : (a0 == 1 ? (ext[0] >= ext[2] ? 0 : 2) : (ext[0] >= ext[1] ? 0 : 1));
+                const uint32_t pp[3] = {r.px, r.py, r.pz};
+                const uint32_t mid0 = (uint32_t)(in.pmin8[a0] + in.pmax8[a0]) << 7, mid1 = (uint32_t)(in.pmin8[a1] + in.pmax8[a1]) << 7;
+                const uint32_t pa0 = a0 == 0 ? pp[0] : (a0 == 1 ? pp[1] : pp[2]), pa1 = a1 == 0 ? pp[0] : (a1 == 1 ? pp[1] : pp[2]);
+                const uint32_t cl = (pa0 >= mid0 ? 1u : 0u) | (pa1 >= mid1 ? 2u : 0u);
+                for (int K2 = 8; K2 <= 16; K2 += 8) {
+                    uint32_t v2 = 0, v4 = 0;
+                    for (uint32_t c = 0; c < 4; ++c) {
+                        for (int pass = 0; pass < 2; ++pass) {           // pass 0: 2-split cluster c (c < 2), pass 1: 4-split cluster c
+                            if (pass == 0 && c >= 2) continue;
+                            const bool mine = live && (pass == 0 ? (cl & 1u) == c : cl == c);
+                            uint32_t red[6];
+                            for (int d = 0; d < 3; ++d) { red[2 * d] = mine ? pp[d] : 0xFFFFFFFFu; red[2 * d + 1] = mine ? ~pp[d] : 0xFFFFFFFFu; }
+                            wave_min_u32(red);
+                            if (red[0] == 0xFFFFFFFFu) continue;     // empty cluster
+                            PlanIn in2 = in;
+                            for (int d = 0; d < 3; ++d) { in2.pmin8[d] = (int32_t)(red[2 * d] >> 8); in2.pmax8[d] = (int32_t)((~red[2 * d + 1] >> 8) + 1); }
+                            Brick b2;
+                            const uint32_t vv = plan_brick(in2, K2, B, kCap, b2);
+                            if (pass == 0) v2 += vv; else v4 += vv;
+                        }
+                    }
+                    stat_add(p, K2 == 8 ? 14 : 16, v2 <= kCap ? 1 : 0);
+                    stat_add(p, K2 == 8 ? 15 : 17, v4 <= kCap ? 1 : 0);
+                }
+            }
 #endif
 #if VRT_PRIO_DIRECT
             __builtin_amdgcn_s_setprio(VRT_PRIO_DIRECT);
@@ -512,9 +583,11 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
             constexpr bool kKeepCorners = sizeof(FieldT) == 2;   // (fp32 at 5 waves/SIMD and 96 registers still spills: 9.5 vs 9.0 ms)
             vox kept[kKeepCorners ? 8 : 1];
             uint32_t have_xy = 0xFFFFFFFFu, have_z = 0xFFFFFFFFu;   // cell of the corners in kept[]: (x | y << 16, z); none yet
-            for (int k = 0; k < kSlabDirectSteps; ++k) {
+            const int direct_steps = SLICED ? (int)(budget < (uint32_t)kSlabDirectSteps ? budget : (uint32_t)kSlabDirectSteps) : kSlabDirectSteps;
+            for (int k = 0; k < direct_steps; ++k) {
                 const bool alive = it > 0 && in_field(r, bx1, by1, bz1);
                 if (!any_lane(alive)) break;
+                if constexpr (SLICED) --budget;
                 stat_add(p, kStatDirectWaveSteps, 1);
                 VRT_TL(++tl_dir);
                 if (alive) {
@@ -553,7 +626,8 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
             const uint32_t lox = bk.lo[0], loy = bk.lo[1], loz = bk.lo[2];
             // two copies of the loop: in a brick without any positive w (the common case) the opacity test
             // cannot fire, so that copy carries neither the test nor the rem_w bookkeeping
-            const int Ku = (int)sgpr((uint32_t)K);                       // keep the trip count in an SGPR
+            // (a slice that ends inside the round simply runs fewer steps of it: the brick planned for K steps holds them)
+            const int Ku = (int)sgpr(SLICED && budget < (uint32_t)K ? budget : (uint32_t)K);   // keep the trip count in an SGPR
             // inside the round the positions are kept relative to the brick origin (its low 16 bits are zero, so
             // the weights and every position update are unchanged): the cell is then one shift, not an SDWA subtract
             const uint32_t ox = lox << 16, oy = loy << 16, oz = loz << 16;
@@ -618,6 +692,7 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                             it -= Kg;
                         }
                         Kr -= (int)Kg;                   // whatever the plan allowed beyond the proof runs with the tests below
+                        if constexpr (SLICED) budget -= Kg;
                     }
 #endif
                 }
@@ -640,6 +715,7 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                     if ((m_pos & m_inb) == 0ull) break;
                     stat_add(p, kStatLdsWaveSteps, 1);
                     VRT_TL(++tl_lds);
+                    if constexpr (SLICED) --budget;
                         if (alive) {
                         bool dark = false;
                         if constexpr (ABSORB) {
@@ -680,6 +756,10 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
             atomicAdd(p.stats + 27, (unsigned long long)tl_lds_total);
             atomicAdd(p.stats + 28, (unsigned long long)tl_dir_total);
             atomicAdd(p.stats + 29, (unsigned long long)tl_rounds_total);
+            atomicAdd(p.stats + 30, (unsigned long long)sl_tickets);
+            atomicAdd(p.stats + 31, (unsigned long long)sl_wasted);
+            atomicAdd(p.stats + 32, (unsigned long long)sl_polls);
+            atomicAdd(p.stats + 33, (unsigned long long)sl_waits);
         }
     };
 #endif
@@ -730,6 +810,86 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                 q[3] = (unsigned long long)tl_rounds | ((unsigned long long)mx << 32);
             }
         }
+#endif
+    } else if constexpr (SLICED) {
+        // Time-sliced persistent wavefronts.  With whole groups as the unit of work a launch of G groups on S slots runs
+        // G / S "rounds" of unequal groups and ends with the GPU draining for as long as the last-started groups take
+        // (tools/timeline.py: 7 .. 13 % of configs 3 and 5 with less than half of the slots busy).  Here the unit is one
+        // SLICE of a group: slice_steps wave-steps.  Work items come from one FIFO: items 0 .. G-1 are the groups in launch
+        // order (fresh rays); a group that still has live rays after its slice parks their state in global memory and
+        // appends itself (ring[tail++ mod R] = group + 1, R >= 2 G: a group is running or queued, never queued twice, so at
+        // most G words are occupied); a wavefront that draws item i >= G waits until its ring word has been written, empties
+        // it, takes over the parked state and marches the next slice.  (A producer that finds its word still occupied -- the
+        // consumer of R items ago has drawn its item but not emptied the word yet -- retries; compare-and-swap makes that exact.)  All groups advance together, so they end
+        // together, and a group resumes on whichever SIMD is free.  An item is only ever appended by a wavefront that is
+        // running, so whoever waits, waits for somebody who makes progress; the waits are bounded all the same and raise
+        // ctr[2] instead of hanging.  ctr[0] head, ctr[1] groups finished, ctr[2] error, ctr[3] tail (items appended).
+        // Counters and queue words are touched by device-scope atomics only: they execute at the coherence point, whereas
+        // a load -- sc1 or not -- may be served a stale line by this XCD's L2 for as long as the line stays there.
+        const uint32_t ngroups = (p.nrays + 63u) >> 6;
+        uint32_t *ctr = p.group_counter;
+        for (;;) {
+            const uint32_t item = lane0_atomic_add(ctr, 1u);
+            VRT_SL(++sl_tickets);
+            uint32_t g;
+            if (item < ngroups) {
+                g = p.wave_order ? sgpr(p.wave_order[item]) : item;
+                begin_group(g * 64u);
+            } else {
+                uint32_t *qe = p.slice_flags + ((item - ngroups) & (p.ticket_limit - 1u));     // ring of ticket_limit = 2^k words
+                uint32_t q = lane0_atomic_add(qe, 0u);
+                VRT_SL(sl_waits += q == 0u ? 1u : 0u);
+                bool finished = false;
+                for (uint32_t spin = 0; q == 0u; ++spin) {
+                    // nothing appended yet: either every group has finished (leave) or a running group will append
+                    if ((spin & 15u) == 0u && lane0_atomic_add(ctr + 1, 0u) >= ngroups) { finished = true; break; }
+                    if (spin >= (1u << 22)) { (void)lane0_atomic_add(ctr + 2, 1u); finished = true; break; }   // never hang
+                    __builtin_amdgcn_s_sleep(127);
+                    q = lane0_atomic_add(qe, 0u);
+                    VRT_SL(++sl_polls);
+                }
+                if (finished) break;
+                (void)lane0_atomic_add(qe, 0u - q);                          // empty the word for its next lap
+                g = q - 1u;
+                slot = g * 64u + lane;
+                have = slot < p.nrays;
+                ray = have ? (p.order ? p.order[slot] : slot) : 0u;
+                const u32x4 *park = (const u32x4 *)p.park + (size_t)g * 128u + lane;      // [group][2][64 lanes] x 16 B
+                u32x4 a, b;
+                load_sc1_2xb128(park, park + 64, a, b);
+                r.px = a.x; r.py = a.y; r.pz = a.z; it = a.w;
+                r.dx = __uint_as_float(b.x); r.dy = __uint_as_float(b.y); r.dz = __uint_as_float(b.z); rem_w = b.w;
+                light = 0xFFFFFFFFu;
+            }
+            budget = p.slice_steps;
+            march();
+            const bool live_left = any_lane(it > 0 && in_field(r, bx1, by1, bz1));
+            if (live_left) {
+                u32x4 *park = (u32x4 *)p.park + (size_t)g * 128u + lane;
+                u32x4 a, b;
+                a.x = r.px; a.y = r.py; a.z = r.pz; a.w = it;
+                b.x = __float_as_uint(r.dx); b.y = __float_as_uint(r.dy); b.z = __float_as_uint(r.dz); b.w = rem_w;
+                store_sc1_b128(park, a);
+                store_sc1_b128(park + 64, b);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the state is out before the group is queued
+                const uint32_t at = lane0_atomic_add(ctr + 3, 1u);
+                uint32_t *qw = p.slice_flags + (at & (p.ticket_limit - 1u));
+                uint32_t spin = 0;
+                while (lane0_atomic_cas(qw, 0u, g + 1u) != 0u) {             // 0 -> g + 1; occupied only in the race described above
+                    if (++spin >= (1u << 22)) { (void)lane0_atomic_add(ctr + 2, 1u); break; }   // never hang
+                    __builtin_amdgcn_s_sleep(16);
+                }
+            } else {
+                if (have) store_ray<DirT>(p, ray, r, rem_w != 0xFFFFFFFFu ? rem_w : it, light);
+                (void)lane0_atomic_add(ctr + 1, 1u);
+            }
+#ifdef VRT_SLAB_PHASES
+            tl_lds_total += tl_lds; tl_dir_total += tl_dir; tl_rounds_total += tl_rounds;
+            tl_lds = tl_dir = tl_rounds = 0;
+#endif
+        }
+#ifdef VRT_SLAB_PHASES
+        ph_flush();
 #endif
     } else {
         // Persistent wavefronts: the grid is what the GPU holds at once and every wavefront draws the next
@@ -814,10 +974,14 @@ hipError_t launch_slab_bytes(const MarchParams &p, int num_cu, hipStream_t s)
         // persistent grid: the wavefronts the GPU holds at once (OCC per SIMD = OCC blocks of 4 wavefronts per CU)
         const unsigned resident = (unsigned)(num_cu > 0 ? num_cu : 256) * (unsigned)OCC;
         const unsigned grid = groups_blocks < resident ? groups_blocks : resident;
-        k_march_slab<FieldT, DirT, VPL, OCC, ABSORB, true><<<grid, threads, lds, s>>>(p);
+        if constexpr (!ABSORB) if (p.park) {
+            k_march_slab<FieldT, DirT, VPL, OCC, ABSORB, 2><<<grid, threads, lds, s>>>(p);
+            return hipGetLastError();
+        }
+        k_march_slab<FieldT, DirT, VPL, OCC, ABSORB, 1><<<grid, threads, lds, s>>>(p);
         return hipGetLastError();
     }
-    k_march_slab<FieldT, DirT, VPL, OCC, ABSORB, false><<<groups_blocks, threads, lds, s>>>(p);
+    k_march_slab<FieldT, DirT, VPL, OCC, ABSORB, 0><<<groups_blocks, threads, lds, s>>>(p);
     return hipGetLastError();
 }
 
