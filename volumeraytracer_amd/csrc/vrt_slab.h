@@ -411,25 +411,42 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
         PlanIn in;
         if ((plan_round++ % VRT_SWEEP_REFRESH) == 0) {
             int32_t s[3];
+            float ilen_lane;
             {                                           // per-step displacement estimate from the current direction
                 const float dot = fma_(r.dz, r.dz, fma_(r.dx, r.dx, r.dy * r.dy));
                 const float ilen = 0x42000000p0f * __builtin_amdgcn_rcpf(dot);   // estimate only
+                ilen_lane = ilen;
                 const float lim = 268435456.0f;         // 2^28
                 s[0] = (int32_t)fminf(fmaxf((r.dx * invx) * ilen, -lim), lim);
                 s[1] = (int32_t)fminf(fmaxf((r.dy * invy) * ilen, -lim), lim);
                 s[2] = (int32_t)fminf(fmaxf((r.dz * invz) * ilen, -lim), lim);
             }
-            uint32_t red[6];                            // min(s_d) and max(s_d) as unsigned minima: bias by 2^31, complement for max
+            uint32_t red[7];                            // min(s_d) and max(s_d) as unsigned minima: bias by 2^31, complement for max
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 red[2 * d] = live ? (uint32_t)s[d] ^ 0x80000000u : 0xFFFFFFFFu;
                 red[2 * d + 1] = live ? ~((uint32_t)s[d] ^ 0x80000000u) : 0xFFFFFFFFu;
             }
+            // the largest C / |dir|^2 of the wave (positive floats order like their bit patterns; NaN / negative -> ignored)
+            red[6] = live && ilen_lane > 0.0f && ilen_lane < 3.0e38f ? ~__float_as_uint(ilen_lane) : 0xFFFFFFFFu;
             wave_min_u32(red);
+            // Bending allowance: the direction changes by at most gstep_d per step, so after j steps the displacement per
+            // step differs from today's by up to j * gstep_d * C / |dir|^2.  Averaged over a round of about 2 * last_rung
+            // steps that is last_rung * gstep_d * ilen per step, on either side.  It makes the planned brick wide enough for
+            // more of the round to be PROVEN (safe_steps): config 3, proven share of the LDS steps 50 % -> 58 %, rounds cut short by
+            // a ray leaving its brick 316 k -> 156 k per launch; run time unchanged within 0.5 % (the tested steps it saves cost
+            // about what the 4 % extra rounds of the slightly wider bricks do).
+            const float ilen_max = red[6] == 0xFFFFFFFFu ? 0.0f : __uint_as_float(~red[6]);
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-                const int32_t smn = (int32_t)(red[2 * d] ^ 0x80000000u);
-                const int32_t smx = (int32_t)(~red[2 * d + 1] ^ 0x80000000u);
+#ifdef VRT_SLAB_NO_BEND
+                const int32_t bend = 0;
+#else
+                const float bf = fminf((float)last_rung * p.gstep[d] * ilen_max * 1.25f, 1048576.0f);
+                const int32_t bend = bf > 0.0f ? (int32_t)bf : 0;         // NaN -> 0
+#endif
+                const int32_t smn = (int32_t)(red[2 * d] ^ 0x80000000u) - bend;
+                const int32_t smx = (int32_t)(~red[2 * d + 1] ^ 0x80000000u) + bend;
                 int32_t a = smn >> 8, c = (smx >> 8) + 1;          // floor / ceil (+1 keeps it conservative)
                 a = a > 0 ? 0 : (a < -(1 << 20) ? -(1 << 20) : a);
                 c = c < 0 ? 0 : (c > (1 << 20) ? (1 << 20) : c);
