@@ -54,11 +54,13 @@ def main():
            "kernel_trace": trace["kernels"], "kernel_stats_rows": trace["stats_rows"], "pmc_per_dispatch": pmc}
     json.dump(out, open(os.path.join(dst, prof_name), "w"), indent=1)
     with open(os.path.join(dst, "%s_kernel_stats_config%d.txt" % (rnd, cfg)), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --cpu-seconds 0 --steps 3 --warmup 1 --config %d\n" % cfg)
+        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --cpu-seconds 0 --steps 4 --warmup 5 --config %d\n" % cfg)
         f.write("%-72s %6s %14s %14s %14s\n" % ("kernel", "calls", "avg_ms", "min_ms", "max_ms"))
         for k, v in sorted(trace["kernels"].items(), key=lambda kv: -kv[1]["total_ns"]):
             f.write("%-72s %6d %14.4f %14.4f %14.4f\n" % (k[:72], v["launches"], v["avg_ns"] / 1e6, v["min_ns"] / 1e6, v["max_ns"] / 1e6))
-    march = [k for k in pmc if "k_march" in k]
+    # the march kernel of the steady state: the schedule the engine settled on has by far the most launches (the other
+    # schedule's kernel appears only in the trial launches of the warm-up)
+    march = sorted([k for k in pmc if "k_march" in k], key=lambda k: -trace["kernels"].get(k, {}).get("launches", 0))
     inter = [k for k in pmc if "k_interleave" in k]
     rj_path = os.path.join(dst, "roofline_inputs.json")
     rj = json.load(open(rj_path)) if os.path.exists(rj_path) else {}

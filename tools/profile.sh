@@ -9,7 +9,8 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --cpu-seconds 0 --steps 3 --warmup 1 $*"
+# warmup 5: the engine settles its schedule choice for the workload during the first four calls (bench.py --warmup)
+BENCH="python3 $REPO/bench.py --cpu-seconds 0 --steps 4 --warmup 5 $*"
 echo "== kernel trace" 
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH > "$OUT/trace.json" 2> "$OUT/trace.err" || echo "trace pass failed"
 python3 $REPO/tools/summarize_prof.py "$OUT/trace" "$OUT/trace_summary.json"; rm -rf "$OUT/trace"
