@@ -691,6 +691,8 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                                     // everything the eight reads need (four addresses) and everything that would otherwise be
                                     // computed into a register one of them is still writing (the weights) comes first, so the
                                     // reads issue back to back and nothing waits on a write-after-read of a load in flight
+                                    // (issuing the reads before the weights, which then cover part of the LDS latency, was
+                                    // measured too: the compiler then waits for all eight reads at once; +2 % on config 4)
                                     uint32_t a0 = lds_addr(seg, mad24(mad24(r.px >> 16, ey, r.py >> 16), ez, r.pz >> 16));
                                     uint32_t a1 = a0 + sy16, a2 = a0 + sx16, a3 = a2 + sy16;
                                     Weights w = lerp_weights(r);
