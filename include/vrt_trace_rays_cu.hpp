@@ -63,8 +63,13 @@ public:
         for (size_t b : output_sizes_) _output_sizes.push_back((uint16_t)b);      // make_struct<uint16_t>, .cu:813
         std::vector<const void *> d;
         for (auto const *v : diff_) d.push_back(v->data());
+        // every visible device, as the reference's constructor replicates onto every CUDA device (.cu:676-686);
+        // trace_rays_cu then marches one band of the rays per device (.cu:804-912)
+        vrt_options o;
+        vrt_options_default(&o);
+        o.devices = -1;
         check(vrt_create(&_h, (int)output_sizes_.size(), _output_sizes.data(), elem_type<DiffType>::value, d.data(),
-                         translucency_cropped_.data(), translucency_cropped_.size(), nullptr));
+                         translucency_cropped_.data(), translucency_cropped_.size(), &o));
     }
 
     TraceRaysCu(std::vector<size_t> const &output_sizes_, std::vector<std::vector<DiffType>> const &diff_,

@@ -6,18 +6,22 @@
 // from global memory on every step (/root/reference/src/cuda_volume_raytracer.cu:138-143 via
 // :397-414).  Here each 64-lane wavefront owns a private LDS segment and repeats:
 //
-//   plan   wave-reduce (DPP) the live lanes' positions and per-step displacement; pick the
+//   plan   batched DPP wave reductions of the live lanes' positions and per-step displacement; pick the
 //          largest step count K whose swept bounding brick (+1 voxel for the upper trilinear
 //          corners), clipped to the field, fits the segment
-//   stage  all 64 lanes copy the brick L2/HBM -> LDS; every lane issues all of its (at most VPL)
-//          16-byte loads before the first LDS write, so one memory latency covers the brick
-//   march  up to K steps with all corners read from LDS (ds_read_b128); a ballot ends the
-//          round as soon as a live lane would leave the brick (rays bend, the plan is only a
+//   stage  all 64 lanes copy the brick L2/HBM -> LDS as fp32 voxels carrying the interpolation's 2^-48 (prescale_ok);
+//          every lane issues all of its (at most VPL) loads before the first LDS write, so one memory latency
+//          covers the brick
+//   march  first the steps during which no lane can PROVABLY leave the brick (safe_steps): a loop with no brick
+//          test, no window test, no ballot; then the rest of the planned K with all corners read from LDS and a
+//          ballot that ends the round as soon as a live lane would leave the brick (rays bend, the plan is only a
 //          prediction) and ends the wavefront when every lane has terminated
 //
-// Wavefronts whose rays do not fit a brick even for one step (incoherent rays) fall back to
+// Wavefronts whose rays do not fit a brick for at least kSlabMinK steps (incoherent rays) fall back to
 // the global gather for a few steps and re-plan.  Waves never synchronise with each other:
 // a 256-thread workgroup is four independent wavefronts with four LDS segments.
+// Scheduling: one wavefront per group of 64 rays (static), persistent wavefronts drawing whole groups from a
+// counter, or persistent wavefronts drawing time slices of groups from a FIFO (SCHED, below).
 #pragma once
 #include <type_traits>
 #include <hip/hip_runtime.h>
@@ -25,17 +29,15 @@
 
 #include "vrt_march.h"
 
-extern "C" __device__ unsigned int __ockl_wfred_min_u32(unsigned int);
-extern "C" __device__ unsigned int __ockl_wfred_max_u32(unsigned int);
-extern "C" __device__ int __ockl_wfred_min_i32(int);
-extern "C" __device__ int __ockl_wfred_max_i32(int);
+extern "C" __device__ unsigned int __ockl_wfred_max_u32(unsigned int);    // development builds only (statistics)
 
 namespace vrt {
 
 constexpr int kSlabWavesPerBlock = 4;
 // A wavefront in global-gather mode is latency-bound (tools/timeline.py: 2.6 us per step against 0.65 us from LDS,
 // and the launch ends with exactly these wavefronts): its few instructions go first.  Measured -2.8 % on config 3,
-// +-1 % on configs 4 and 5; priority for the first-launched groups as well gave nothing more.
+// +-1 % on configs 4 and 5 (round 1).  Raised priority for the 256 ... 2048 longest groups over their whole life was
+// measured in round 2: no effect at any count.
 #ifndef VRT_PRIO_DIRECT
 #define VRT_PRIO_DIRECT 3
 #endif
