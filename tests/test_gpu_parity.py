@@ -435,6 +435,12 @@ def test_denormal_scale_gradients_and_invscale(kernel):
     cases.append((1e-41, 1e-40, [1.0, 2.0, 0.5]))          # denormal field values
     cases.append((1.0, 1e-3, [1e-25, 1e-25, 1e-25]))       # invscale < 2^-78
     cases.append((1e-12, 1e-9, [1.0, 1.0, 1.0]))           # small but normal throughout
+    # the other end: the reference multiplies by weights of up to 2^48 in total BEFORE its final 2^-48, so values beyond
+    # 2^128 / 2^48 overflow to infinity inside the interpolation; LDS bricks carry the 2^-48 up front and must not be
+    # used for such voxels (prescale_ok, vrt_slab.h) -- well above, around and just below that edge
+    cases.append((3e27, 1.0, [1.0, 1.0, 1.0]))
+    cases.append((4e23, 1.0, [1.0, 1.0, 1.0]))
+    cases.append((1e23, 1.0, [1.0, 0.5, 2.0]))
     for gs, ds, inv in cases:
         d = [(rng.randn(n) * gs).astype(np.float32) for _ in range(3)]
         field = oracle.port.interleave(d[0], d[1], d[2], tc)

@@ -212,7 +212,9 @@ __device__ __forceinline__ Weights lerp_weights(const Ray &r)
 }
 // WINDOW_TEST = false: the caller has proven that |dir|^2 stays inside the fast-path window for the whole round
 // (safe_steps, vrt_slab.h), so the step carries no test at all.
-template <bool PRESCALED, bool WINDOW_TEST>
+// UNIT_INV = true: invscale is exactly (1, 1, 1) (every BASELINE config): fma(g, 1, d) == g + d and d * 1 == d bit for bit,
+// so the three products with invscale are not computed.
+template <bool PRESCALED, bool WINDOW_TEST, bool UNIT_INV = false>
 __device__ __forceinline__ void march_step_now(Ray &r, const f4 (&c)[8], const Weights &w, float invx, float invy, float invz, StepWindow win)
 {
     const float wrx = w.wrx, wlx = w.wlx, wry = w.wry, wly = w.wly, wrz = w.wrz, wlz = w.wlz;
@@ -228,11 +230,10 @@ __device__ __forceinline__ void march_step_now(Ray &r, const f4 (&c)[8], const W
         VRT_CH(x, g[0]) VRT_CH(y, g[1]) VRT_CH(z, g[2])
 #undef VRT_CH
     }
-    r.dx = fma_(g[0], invx, r.dx);
-    r.dy = fma_(g[1], invy, r.dy);
-    r.dz = fma_(g[2], invz, r.dz);
+    if constexpr (UNIT_INV) { r.dx = g[0] + r.dx; r.dy = g[1] + r.dy; r.dz = g[2] + r.dz; }
+    else { r.dx = fma_(g[0], invx, r.dx); r.dy = fma_(g[1], invy, r.dy); r.dz = fma_(g[2], invz, r.dz); }
     const float dot = fma_(r.dz, r.dz, fma_(r.dx, r.dx, r.dy * r.dy));
-    const float ex = r.dx * invx, ey = r.dy * invy, ez = r.dz * invz;
+    const float ex = UNIT_INV ? r.dx : r.dx * invx, ey = UNIT_INV ? r.dy : r.dy * invy, ez = UNIT_INV ? r.dz : r.dz * invz;
     const float ilen2 = ilen2_short(dot);                   // garbage outside the window, replaced below
     uint32_t sx = round_half_i32(ex * ilen2), sy = round_half_i32(ey * ilen2), sz = round_half_i32(ez * ilen2);
     const bool outside = WINDOW_TEST && !((__float_as_uint(dot) - win.lo) < win.span);

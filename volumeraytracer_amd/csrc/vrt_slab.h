@@ -292,12 +292,15 @@ __device__ __forceinline__ vox_f32 to_f32_vox(const vox_i16 &v)
 // long as no intermediate of the scaled computation is subnormal.  With all non-zero inputs at least 2^-55 in magnitude
 // every intermediate of the unscaled computation is a multiple of 2^-78 (products with the integer weights and their
 // sums keep that grid, and rounding a multiple of 2^-78 to 24 bits keeps it too), hence zero or at least 2^-78 and, scaled,
-// zero or at least 2^-126: normal.  prescale_ok() is that input condition; a brick that fails it is not staged
+// zero or at least 2^-126: normal.  prescale_ok() is that input condition (plus an upper bound against overflow); a brick that fails it is not staged
 // (the round gathers from global memory, unscaled), which is what keeps the results bit-identical.
 __device__ __forceinline__ bool prescale_ok(const vox_f32 &v)
 {
-    auto ok = [](float a) { const uint32_t b = __float_as_uint(a) & 0x7FFFFFFFu; return b == 0u || b >= ((127u - 55u) << 23); };
-    return ok(v.x) && ok(v.y) && ok(v.z);                 // (NaN / inf pass: they are NaN / inf either way)
+    // ... and below 2^78: the unscaled computation multiplies by weights of up to 2^48 in total before its final 2^-48, so
+    // a larger value overflows to infinity there (and must here too); NaN and infinity fail the test as well.  Such bricks
+    // take the unscaled global-gather path.
+    auto ok = [](float a) { const uint32_t b = __float_as_uint(a) & 0x7FFFFFFFu; return b == 0u || (b >= ((127u - 55u) << 23) && b < ((127u + 78u) << 23)); };
+    return ok(v.x) && ok(v.y) && ok(v.z);
 }
 __device__ __forceinline__ bool prescale_ok(const vox_i16 &) { return true; }   // |v| >= 1 or 0
 __device__ __forceinline__ vox_f32 prescaled(vox_f32 v)
@@ -688,7 +691,7 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                         VRT_TL(tl_lds += Kg);
                         if (pos0) {
                             const uint32_t sy16 = sy * (uint32_t)sizeof(lvox), sx16 = sx * (uint32_t)sizeof(lvox);
-                            auto proven = [&](auto window_test) {
+                            auto proven = [&](auto window_test, auto unit_inv) {
                                 for (uint32_t k = 0; k < Kg; ++k) {
                                     // everything the eight reads need (four addresses) and everything that would otherwise be
                                     // computed into a register one of them is still writing (the weights) comes first, so the
@@ -706,10 +709,16 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                                     f4 c[8];
 #pragma unroll
                                     for (int q = 0; q < 8; ++q) cvt_vox(v[q], c[q]);
-                                    march_step_now<kPrescaled, decltype(window_test)::value>(r, c, w, invx, invy, invz, win);
+                                    march_step_now<kPrescaled, decltype(window_test)::value, decltype(unit_inv)::value>(r, c, w, invx, invy, invz, win);
                                 }
                             };
-                            if (win_all) proven(std::false_type{}); else proven(std::true_type{});
+#ifdef VRT_SLAB_NO_UNIT_INV
+                            const bool unit_inv = false;
+#else
+                            const bool unit_inv = invx == 1.0f && invy == 1.0f && invz == 1.0f;      // wave-uniform (kernel arguments)
+#endif
+                            if (win_all) { if (unit_inv) proven(std::false_type{}, std::true_type{}); else proven(std::false_type{}, std::false_type{}); }
+                            else proven(std::true_type{}, std::false_type{});
                             it -= Kg;
                         }
                         Kr -= (int)Kg;                   // whatever the plan allowed beyond the proof runs with the tests below
