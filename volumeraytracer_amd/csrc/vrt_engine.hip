@@ -162,6 +162,7 @@ struct vrt_engine {
     size_t field_bytes = 0;
     int num_cu = 256;
     float gmax[3] = {INFINITY, INFINITY, INFINITY};   // max |field channel| over the whole field (proven rounds, vrt_slab.h: safe_steps)
+    float gnorm = INFINITY;                            // >= max over the field of the gradient vector's length
     DevBuf transl;                 // translucency per field voxel, kept only for the opt-in absorption mode
     Workspace ws[kLanes];
     std::mutex mu;                 // device-pointer calls: one host thread at a time inside an engine
@@ -223,17 +224,19 @@ int launch_interleave(vrt_engine *e, const void *const d_diff[3], const uint32_t
 // Non-negative floats order like their bit patterns, and a NaN's pattern is above infinity's: an atomic max on the
 // patterns of |v| returns the largest magnitude, or a NaN if the field holds one (which then disables proven rounds).
 template <typename VoxT>
-__global__ __launch_bounds__(256) void k_field_absmax(const VoxT *f, size_t n, uint32_t *out /* [3] */)
+__global__ __launch_bounds__(256) void k_field_absmax(const VoxT *f, size_t n, uint32_t *out /* [4]: |x|, |y|, |z|, x^2+y^2+z^2 */)
 {
-    uint32_t m[3] = {0u, 0u, 0u};
+    uint32_t m[4] = {0u, 0u, 0u, 0u};
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const VoxT v = f[i];
         const float a[3] = {(float)v.x, (float)v.y, (float)v.z};
 #pragma unroll
         for (int d = 0; d < 3; ++d) { const uint32_t b = __float_as_uint(a[d]) & 0x7FFFFFFFu; m[d] = b > m[d] ? b : m[d]; }
+        const uint32_t q = __float_as_uint(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]) & 0x7FFFFFFFu;   // squared length of the gradient vector
+        m[3] = q > m[3] ? q : m[3];
     }
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
+    for (int d = 0; d < 4; ++d) {
         for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)m[d], o); m[d] = t > m[d] ? t : m[d]; }
         if ((threadIdx.x & 63u) == 0) atomicMax(&out[d], m[d]);
     }
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(256) void k_field_absmax(const VoxT *f, size_t n, u
 
 int engine_field_absmax(vrt_engine *e, hipStream_t s)
 {
-    uint32_t *d_out = nullptr, h[3] = {0, 0, 0};
+    uint32_t *d_out = nullptr, h[4] = {0, 0, 0, 0};
     HIP_TRY(hipMalloc(&d_out, sizeof h));
     hipError_t err = hipMemsetAsync(d_out, 0, sizeof h, s);
     if (err == hipSuccess) {
@@ -254,7 +257,10 @@ int engine_field_absmax(vrt_engine *e, hipStream_t s)
     if (err == hipSuccess) err = hipStreamSynchronize(s);
     (void)hipFree(d_out);
     HIP_TRY(err);
-    memcpy(e->gmax, h, sizeof h);
+    memcpy(e->gmax, h, 3 * sizeof(uint32_t));
+    float q;
+    memcpy(&q, &h[3], 4);
+    e->gnorm = (float)(std::sqrt((double)q) * (1.0 + 1.0 / 1024.0));     // >= the longest gradient vector (float sum of squares: 3 roundings)
     return VRT_OK;
 }
 
@@ -415,6 +421,14 @@ int trace_device_impl(vrt_engine *e, Workspace &w, int dir_type, size_t nrays, c
         float gf = (float)g;
         if ((double)gf < g) gf = std::nextafterf(gf, INFINITY);
         p.gstep[d] = gf;                                 // NaN / inf stay what they are: no round is proven then
+    }
+    {   // the direction VECTOR changes by at most max|inv_d| x (longest gradient vector) per step: the interpolated gradient is
+        // a convex combination of the corner vectors
+        const double im = std::max(std::fabs((double)invscale[0]), std::max(std::fabs((double)invscale[1]), std::fabs((double)invscale[2])));
+        const double g = (double)e->gnorm * im * (1.0 + 1.0 / 1048576.0);
+        float gf = (float)g;
+        if ((double)gf < g) gf = std::nextafterf(gf, INFINITY);
+        p.gstep_norm = gf;
     }
     p.start_pos = d_sp; p.start_dir = d_sd;
     p.end_pos = d_ep; p.end_dir = d_ed; p.end_iter = d_ei; p.remaining_light = d_rl;
@@ -834,6 +848,7 @@ int engine_replicate(vrt_engine *e)
         rc = engine_init_device(r);
         if (rc) return rc;
         memcpy(r->gmax, e->gmax, sizeof r->gmax);
+        r->gnorm = e->gnorm;
         hipStream_t s = r->ws[0].stream;
         if (r->device != e->device) {
             int can = 0;

@@ -231,7 +231,10 @@ __device__ __forceinline__ uint32_t plan_brick(const PlanIn &in, int K, const ui
 //   combination; its three fma levels and the exact 2^-48 add a factor (1 + 2^-20) at most, and the fma of the update
 //   at most |D| * 2^-23 -- both covered by `slack` below);
 //   pos_d += s_d,  s_d = roundf(E_d * (C / dot)),  |s_d| <= |E_d| * C / dot * (1 + 2^-20) + 0.5, sign(s_d) = sign(E_d).
-// Over j <= K steps |D_d| grows by at most K G_d and |D| shrinks by at most R := K (Gx + Gy + Gz).  With rho := R / |D| <= 1/4:
+// Over j <= K steps |D_d| grows by at most K G_d and |D| shrinks by at most R := K Gn, Gn := gstep_norm >= the length of g * inv
+// (the interpolated gradient is a convex combination of corner vectors, so it is no longer than the longest one; taking the
+// sum Gx + Gy + Gz instead made rho about 2.5 x larger and proved 58 % of config 3's LDS steps instead of 64 %; the
+// launch time did not move, as with every other saving inside the LDS step in round 2).  With rho := R / |D| <= 1/4:
 //   C / dot_j <= C / (dot (1 - rho)^2),
 // so every step moves the ray by at most  up_d = (max(E_d, 0) + K G_d |inv_d|) * C / (dot (1 - rho)^2) + 0.5  towards +d and by
 // at most dn_d (the same with max(-E_d, 0)) towards -d (rho is evaluated 2^-9 too large and the quotient 2^-9 too large again).  The ray gathers at positions p, p + s_1, ... before steps 0, 1, ...:
@@ -243,7 +246,7 @@ __device__ __forceinline__ uint32_t plan_brick(const PlanIn &in, int K, const ui
 // value for K steps, so dot stays within [0.5625, 1.5625] dot (1 +- 2^-21); if [0.55, 1.6] dot lies strictly inside
 // the window now, no step of the round can leave it and the loop needs no window test (`window_ok`).
 __device__ __forceinline__ uint32_t safe_steps(const Ray &r /* relative to the brick origin */, float invx, float invy, float invz,
-                                               float gx, float gy, float gz, int K, uint32_t hx, uint32_t hy, uint32_t hz /* H_d - 1 */,
+                                               float gx, float gy, float gz, float gnorm, int K, uint32_t hx, uint32_t hy, uint32_t hz /* H_d - 1 */,
                                                StepWindow win, bool &window_ok)
 {
     const float dot = fma_(r.dz, r.dz, fma_(r.dx, r.dx, r.dy * r.dy));
@@ -252,7 +255,11 @@ __device__ __forceinline__ uint32_t safe_steps(const Ray &r /* relative to the b
     const float Kf = (float)K;
     const float slack = len * 0x1p-21f;
     const float Gx = gx + slack, Gy = gy + slack, Gz = gz + slack;
+#ifdef VRT_SLAB_L1_SHRINK
     const float R = Kf * ((Gx + Gy) + Gz);
+#else
+    const float R = Kf * (gnorm + 2.0f * slack);                          // |D| shrinks by at most the LENGTH of the gradient per step
+#endif
     const bool ok = R * 4.0f <= len;                                      // false for NaN / inf / tiny directions
     const float rho = (R * 1.002f) * __builtin_amdgcn_rcpf(len);          // >= R / |D|
     const float shrink = __builtin_amdgcn_rcpf(1.0f - rho);               // 1 / (1 - rho), rho <= 0.2505
@@ -674,7 +681,7 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                     // proven part of the round: no lane can leave the brick during Kg steps (safe_steps), so the loop
                     // carries no brick test, no ballot and no exit -- lanes not live at the start of the round stay masked
                     bool win_mine = true;
-                    const uint32_t mine = pos0 ? safe_steps(r, invx, invy, invz, p.gstep[0], p.gstep[1], p.gstep[2], Ku,
+                    const uint32_t mine = pos0 ? safe_steps(r, invx, invy, invz, p.gstep[0], p.gstep[1], p.gstep[2], p.gstep_norm, Ku,
                                                              (ex1 << 16) - 1u, (ey1 << 16) - 1u, (ez1 << 16) - 1u, win, win_mine)
                                                : 0xFFFFFFFFu;
                     const bool win_all = !any_lane(pos0 && !win_mine);
