@@ -127,13 +127,14 @@ struct Workspace {
     bool last_sliced = false;                          // the lane's most recent march used the time-sliced schedule
     // Schedule auto-tuning (vrt_options.schedule = 0): whether time slicing pays depends on how unevenly the groups of a
     // launch run, which is not known beforehand (config 5: 14.7 -> 13.7 ms; a 1448 x 1448 lattice on 512^3: 13.8 -> 15.5).
-    // The first launches of a workload shape alternate between the whole-group and the time-sliced schedule, HIP events
-    // around each; once the second pair has finished (hipEventQuery, never a wait) the faster one is kept for that shape.
+    // The first four launches of a workload shape alternate between the whole-group and the time-sliced schedule, HIP
+    // events around each; once they have finished (hipEventQuery, never a wait) the schedule with the smaller minimum of
+    // its two trials is kept for that shape (one trial each flipped the choice on a 3 % difference now and then).
     struct Tuner {
         unsigned long long key = 0;
         int state = 0;                                 // 0..3: trial launches (2, 3, 2, 3); 4: waiting for the events; 5: decided
         int choice = 2;
-        hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [schedule 2 | 3][begin | end] of the second trial pair
+        hipEvent_t ev[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // [trial][begin | end]
         float ms[2] = {0.0f, 0.0f};
     } tuner;
     DevBuf sort_keys, sort_keys_alt, sort_vals, sort_vals_alt, sort_tmp, sort_bounds;
@@ -319,8 +320,8 @@ int workspace_init(Workspace &w)
 void workspace_free(Workspace &w)
 {
     if (w.stream) { (void)hipStreamSynchronize(w.stream); (void)hipStreamDestroy(w.stream); }
-    for (hipEvent_t ev : {w.ev_begin, w.ev_end, w.ev_done, w.tuner.ev[0][0], w.tuner.ev[0][1], w.tuner.ev[1][0], w.tuner.ev[1][1]})
-        if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : {w.ev_begin, w.ev_end, w.ev_done}) if (ev) (void)hipEventDestroy(ev);
+    for (auto &pair : w.tuner.ev) for (hipEvent_t ev : pair) if (ev) (void)hipEventDestroy(ev);
     for (DevBuf *b : w.all) b->release();
     w.err.release();
     if (w.pin_err) (void)hipHostFree(w.pin_err);
@@ -511,17 +512,19 @@ int trace_device_impl(vrt_engine *e, Workspace &w, int dir_type, size_t nrays, c
                 if (t.key != key) { t.key = key; t.state = 0; t.choice = 2; }
                 if (t.state < 4) {
                     schedule = (t.state & 1) ? 3 : 2;
-                    if (t.state >= 2) {
-                        trial = t.state & 1;
-                        for (int k = 0; k < 2; ++k) if (!t.ev[trial][k]) HIP_TRY(hipEventCreate(&t.ev[trial][k]));
-                    }
+                    trial = t.state;
+                    for (int k = 0; k < 2; ++k) if (!t.ev[trial][k]) HIP_TRY(hipEventCreate(&t.ev[trial][k]));
                     ++t.state;
                 } else if (t.state == 4) {
                     schedule = 2;
-                    if (hipEventQuery(t.ev[0][1]) == hipSuccess && hipEventQuery(t.ev[1][1]) == hipSuccess &&
-                        hipEventElapsedTime(&t.ms[0], t.ev[0][0], t.ev[0][1]) == hipSuccess &&
-                        hipEventElapsedTime(&t.ms[1], t.ev[1][0], t.ev[1][1]) == hipSuccess) {
-                        t.choice = t.ms[1] < 0.98f * t.ms[0] ? 3 : 2;
+                    float ms[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    bool ready = true;
+                    for (int k = 0; k < 4 && ready; ++k)
+                        ready = hipEventQuery(t.ev[k][1]) == hipSuccess && hipEventElapsedTime(&ms[k], t.ev[k][0], t.ev[k][1]) == hipSuccess;
+                    if (ready) {
+                        t.ms[0] = std::min(ms[0], ms[2]);
+                        t.ms[1] = std::min(ms[1], ms[3]);
+                        t.choice = t.ms[1] < 0.985f * t.ms[0] ? 3 : 2;
                         t.state = 5;
                         schedule = t.choice;
                         if (o.loglevel < 0) printf("schedule tuned: whole groups %.3f ms, time-sliced %.3f ms -> %d\n", t.ms[0], t.ms[1], t.choice);
