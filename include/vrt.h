@@ -187,6 +187,11 @@ int vrt_engine_debug_stats(vrt_handle h, unsigned long long *out, int n);
  * compares it with the IEEE quotient.  *mismatches must come back 0; *admitted = number of patterns
  * taking the short path (219 exponents x 2^23 mantissas). */
 int vrt_selftest_ilen2(int device, unsigned long long *mismatches, unsigned long long *admitted);
+/* Exhaustive device self-test of the position update pos += roundf(s) (cuda_volume_raytracer.cu:347, std::round on the
+ * step) as the march kernels compute it inside the step window (v_cvt_rpi_i32_f32 on |s|, sign folded into the add):
+ * every float with |s| < 2^31 against std::round + the x86 conversion.  *mismatches must come back 0;
+ * *checked = 2 x 158 x 2^23 patterns. */
+int vrt_selftest_round(int device, unsigned long long *mismatches, unsigned long long *checked);
 
 /* ---------------------------------------------------------------------------------------------
  * Scene layer: the reference's RaytraceScene<Ior,IorLog,Diff>

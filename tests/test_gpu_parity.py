@@ -307,6 +307,16 @@ def test_short_division_is_exact_for_every_admitted_float():
 
 
 @pytest.mark.gpu
+def test_position_update_is_exact_for_every_step_below_2_31():
+    """Inside the step window the march adds roundf(s) to the position through v_cvt_rpi_i32_f32(|s|) with the sign folded
+    into the add (vrt_march.h: add_round): the device sweeps every float with |s| < 2^31 against std::round + cvttss2si
+    (.cu:347).  Integer-exact: 0 mismatches."""
+    bad, checked = capi.selftest_round(0)
+    assert bad == 0
+    assert checked == 2 * 158 * (1 << 23)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fdt", [np.float32, np.int16])
 @pytest.mark.parametrize("ddt", [np.float32, np.int16])
 def test_persistent_schedule(fdt, ddt):
@@ -412,6 +422,38 @@ def test_step_window_boundary(kernel):
             sd = (u * mag[:, None]).astype(np.float32).reshape(-1)
             want = oracle.port.trace(field, B, sp, sd, inv, 6)
             got = eng.trace(sp, sd, inv, 6, options=_opts(kernel))
+            _assert_same(got, want, ctx="inv=%s" % (inv,))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_quotient_at_the_edge_of_overflow(kernel):
+    """|dir|^2 so small that 0x42000000p0f / |dir|^2 lies within a factor 4 of FLT_MAX (internal |dir| around 2^-48, i.e.
+    caller-scale 2^-64): the step (dir * inv) * ilen must be formed exactly as the reference writes it (.cu:346-347) --
+    a component that is zero or denormal gives 0 or a small step while the others saturate to INT_MIN (cvttss2si), and
+    any re-association (such as doubling ilen first, which overflows one binade earlier) turns that component into
+    inf * 0 = NaN -> INT_MIN as well."""
+    rng = np.random.RandomState(31)
+    B = [12, 13, 14]
+    n = B[0] * B[1] * B[2]
+    d = [(rng.randn(n) * 1e-30).astype(np.float32) for _ in range(3)]
+    tc = np.full(n, 0xFFFFFFFF, np.uint32)
+    field = oracle.port.interleave(d[0], d[1], d[2], tc)
+    m = 8192
+    pv = 1.0 + rng.rand(m, 3) * (np.array(B) - 3.0)
+    sp = np.round(pv * 65536).astype(np.uint32).reshape(-1)
+    u = rng.randn(m, 3)
+    u /= np.linalg.norm(u, axis=1)[:, None]
+    mag = 2.0 ** rng.uniform(-66.5, -62.0, m)                 # the quotient overflows below about 2^-64.5
+    dirs = (u * mag[:, None]).astype(np.float32)
+    dirs[::3, 0] = 0.0                                        # exactly zero components
+    dirs[1::5, 1] = (rng.randn(dirs[1::5].shape[0]) * 1e-42).astype(np.float32)   # denormal components
+    dirs[2::7, 2] *= np.float32(1e-12)                        # tiny but normal
+    sd = dirs.reshape(-1)
+    with capi.Engine.from_host(B, d, tc) as eng:
+        for inv in ([1, 1, 1], [2.0, 0.5, 1.0]):
+            want = oracle.port.trace(field, B, sp, sd, inv, 5)
+            got = eng.trace(sp, sd, inv, 5, options=_opts(kernel))
             _assert_same(got, want, ctx="inv=%s" % (inv,))
 
 

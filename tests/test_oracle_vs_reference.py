@@ -47,6 +47,37 @@ def test_seam_random(fdt, ddt, opaque):
                 assert np.array_equal(r[k].view(np.uint8), p[k].view(np.uint8)), (k, inv, iters)
 
 
+def test_seam_quotient_at_the_edge_of_overflow():
+    """Same inputs as tests/test_gpu_parity.py::test_quotient_at_the_edge_of_overflow: |dir|^2 so small that the step's
+    quotient 0x42000000p0f / |dir|^2 is within a factor 4 of FLT_MAX, with zero / denormal components."""
+    rng = np.random.RandomState(31)
+    B = [12, 13, 14]
+    n = B[0] * B[1] * B[2]
+    d = [(rng.randn(n) * 1e-30).astype(np.float32) for _ in range(3)]
+    tc = np.full(n, 0xFFFFFFFF, np.uint32)
+    field = oracle.port.interleave(d[0], d[1], d[2], tc)
+    m = 8192
+    pv = 1.0 + rng.rand(m, 3) * (np.array(B) - 3.0)
+    sp = np.round(pv * 65536).astype(np.uint32).reshape(-1)
+    u = rng.randn(m, 3)
+    u /= np.linalg.norm(u, axis=1)[:, None]
+    mag = 2.0 ** rng.uniform(-66.5, -62.0, m)
+    dirs = (u * mag[:, None]).astype(np.float32)
+    dirs[::3, 0] = 0.0
+    dirs[1::5, 1] = (rng.randn(dirs[1::5].shape[0]) * 1e-42).astype(np.float32)
+    dirs[2::7, 2] *= np.float32(1e-12)
+    sd = dirs.reshape(-1)
+    for inv in ((1, 1, 1), (2.0, 0.5, 1.0)):
+        r = oracle.ref.seam_trace(B, d[0], d[1], d[2], tc, sp, sd, inv, 5)
+        p = oracle.port.trace(field, B, sp, sd, inv, 5)
+        for k in ("end_position", "end_direction", "end_iteration"):
+            assert np.array_equal(r[k].view(np.uint8), p[k].view(np.uint8)), (k, inv)
+    # the case is live: some rays see a saturated component (INT_MIN step) next to an untouched one
+    delta = p["end_position"].reshape(-1, 3) - sp.reshape(-1, 3)                     # uint32, wraps
+    sat = delta == 0x80000000
+    assert (sat.any(axis=1) & (~sat & (delta != 0)).any(axis=1)).sum() > 100
+
+
 @pytest.mark.parametrize("dti,dtd", [(np.float32, np.float32), (np.uint32, np.int16)])
 def test_scene_random(dti, dtd):
     N = 22

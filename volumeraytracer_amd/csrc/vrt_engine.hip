@@ -797,7 +797,7 @@ struct vrt_scene {
 // =============================================================================================
 
 
-// Exhaustive self-test of the march step's short division (vrt_march.h: ilen2_short / div_window):
+// Exhaustive self-test of the march step's short division (vrt_march.h: ilen_short / div_window):
 // one block per (sign, biased exponent), threads sweep all 2^23 mantissas.
 __global__ __launch_bounds__(256) void k_selftest_ilen2(unsigned long long *out /* [2]: mismatches, admitted */)
 {
@@ -808,10 +808,28 @@ __global__ __launch_bounds__(256) void k_selftest_ilen2(unsigned long long *out 
         if (!vrt::div_window(d)) continue;
         ++adm;
         const float q = 0x42000000p0f / d;                                   // IEEE divide, as .cu:346
-        bad += __float_as_uint(vrt::ilen2_short(d)) != __float_as_uint(q + q);
+        bad += __float_as_uint(vrt::ilen_short(d)) != __float_as_uint(q);
     }
     for (int o = 32; o > 0; o >>= 1) { bad += __shfl_xor(bad, o); adm += __shfl_xor(adm, o); }
     if ((threadIdx.x & 63u) == 0) { atomicAdd(&out[0], bad); atomicAdd(&out[1], adm); }
+}
+
+// Exhaustive self-test of the march step's position update (vrt_march.h: add_round): every float s with |s| < 2^31 (both
+// signs, biased exponents 0..157, all mantissas) against std::round + cvttss2si as the reference computes the step (.cu:347).
+__global__ __launch_bounds__(256) void k_selftest_round(unsigned long long *out /* [2]: mismatches, checked */)
+{
+    const uint32_t expo = blockIdx.x & 255u, sign = blockIdx.x >> 8;
+    unsigned long long bad = 0, n = 0;
+    const uint32_t pos0 = 0x12345678u + blockIdx.x * 0x9E3779B9u;
+    for (uint32_t m = threadIdx.x; m < (1u << 23); m += blockDim.x) {
+        const float v = __uint_as_float((sign << 31) | (expo << 23) | m);
+        if (expo <= 157u) {
+            ++n;
+            bad += vrt::add_round(pos0, v) != pos0 + (uint32_t)vrt::round_to_i32(v);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { bad += __shfl_xor(bad, o); n += __shfl_xor(n, o); }
+    if ((threadIdx.x & 63u) == 0) { atomicAdd(&out[0], bad); atomicAdd(&out[1], n); }
 }
 
 // Devices a new handle spans: vrt_options.devices is a bit mask of HIP ordinals (0 = just vrt_options.device, -1 = every
@@ -1369,6 +1387,24 @@ int vrt_selftest_ilen2(int device, unsigned long long *mismatches, unsigned long
     HIP_TRY(e);
     *mismatches = h_out[0];
     *admitted = h_out[1];
+    return VRT_OK;
+}
+
+int vrt_selftest_round(int device, unsigned long long *mismatches, unsigned long long *checked)
+{
+    if (!mismatches || !checked) return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_selftest_round: null output");
+    DeviceGuard g(device);
+    if (!g.ok) return fail(VRT_ERR_NO_DEVICE, "vrt_selftest_round: cannot select device");
+    unsigned long long *d_out = nullptr, h_out[2] = {0, 0};
+    HIP_TRY(hipMalloc(&d_out, sizeof(h_out)));
+    hipError_t e = hipMemset(d_out, 0, sizeof(h_out));
+    if (e == hipSuccess) { k_selftest_round<<<512, 256>>>(d_out); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(h_out, d_out, sizeof(h_out), hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);
+    HIP_TRY(e);
+    *mismatches = h_out[0];
+    *checked = h_out[1];
     return VRT_OK;
 }
 

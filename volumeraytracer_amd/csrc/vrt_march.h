@@ -72,14 +72,7 @@ __device__ __forceinline__ int32_t round_to_i32(float x)
     return r;
 }
 
-// roundf(t/2) as uint32 two's complement for |t| < 2^31, t = 2s exact (see march_step)
-__device__ __forceinline__ uint32_t round_half_i32(float t)
-{
-    const int32_t i = (int32_t)t;                       // v_cvt_i32_f32 truncates toward zero
-    return (uint32_t)((i + 1 + (i >> 31)) >> 1);
-}
-
-// 2 * (0x42000000p0f / d) without the 11-instruction IEEE sequence: v_rcp_f32 (1 ulp) and one fma
+// 0x42000000p0f / d without the 11-instruction IEEE sequence: v_rcp_f32 (1 ulp) and one fma
 // refinement of the quotient.  tools/ubench/div_exact.hip and vrt_selftest_ilen2() compare this against
 // the IEEE divide for EVERY mantissa of every exponent: it is bit-identical for biased exponents 31..252
 // of d (below, the quotient overflows; above, the reciprocal is denormal).  div_window() admits 32..250.
@@ -87,11 +80,29 @@ __device__ __forceinline__ bool div_window(float d)
 {
     return (__float_as_uint(d) - (32u << 23)) < ((251u - 32u) << 23);   // sign bit set / NaN / inf wrap out of range
 }
-__device__ __forceinline__ float ilen2_short(float d)
+__device__ __forceinline__ float ilen_short(float d)
 {
     const float r = __builtin_amdgcn_rcpf(d);
-    const float q = 0x84000000p0f * r;
-    return fma_(fma_(-d, q, 0x84000000p0f), r, q);
+    const float q = 0x42000000p0f * r;
+    return fma_(fma_(-d, q, 0x42000000p0f), r, q);
+}
+
+// pos + roundf(s) for |s| < 2^31: v_cvt_rpi_i32_f32 is floor(x + 0.5) evaluated exactly (vrt_selftest_round() checks every
+// float below 2^31 on the caller's GPU), which on |s| is round-half-away-from-zero of the magnitude; the sign goes back
+// in as a two's-complement negate folded into the add: (m ^ sg) + pos - sg with sg = 0 or -1.
+__device__ __forceinline__ uint32_t rpi_abs(float s)
+{
+    uint32_t m;
+    asm("v_cvt_rpi_i32_f32 %0, |%1|" : "=v"(m) : "v"(s));
+    return m;
+}
+__device__ __forceinline__ uint32_t add_round(uint32_t pos, float s)
+{
+    const uint32_t m = rpi_abs(s);
+    const uint32_t sg = (uint32_t)((int32_t)__float_as_uint(s) >> 31);
+    uint32_t t;
+    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(t) : "v"(m), "v"(sg), "v"(pos));
+    return t - sg;
 }
 
 // ---- voxel pair loads: voxel z and z+1 at one (x,y), as 2 x f4 --------------------------
@@ -176,25 +187,19 @@ __device__ __forceinline__ bool march_step(Ray &r, const f4 (&c)[8], float invx,
     r.dz = fma_(g[2], invz, r.dz);
     const float dot = fma_(r.dz, r.dz, fma_(r.dx, r.dx, r.dy * r.dy));
     // The step s = (dir*inv)*ilen, ilen = 0x42000000p0f / dot (IEEE divide, .cu:346-347), is needed only
-    // through roundf(s).  Doubling is exact and commutes with the rounding of the product, so
-    // t = (dir*inv)*(2*ilen) == 2s bit for bit; its truncation keeps the half bit and
-    // roundf(s) == (trunc(2s) + 1 + sign) >> 1 (arithmetic): for trunc >= 0 that is (t+1)>>1, for
-    // trunc < 0 it is floor(t/2), i.e. round half away from zero.
-    auto round_slow = [&r](float tx, float ty, float tz) {  // NaN / inf / out of range: x86 cvttss2si semantics
-        r.px += (uint32_t)round_to_i32(tx * 0.5f);
-        r.py += (uint32_t)round_to_i32(ty * 0.5f);
-        r.pz += (uint32_t)round_to_i32(tz * 0.5f);
-    };
+    // through roundf(s): inside the window the short division and add_round (v_cvt_rpi_i32_f32 on |s|, both verified
+    // exhaustively on the device: vrt_selftest_ilen2, vrt_selftest_round) replace the divide and std::round.
     if (!((__float_as_uint(dot) - win.lo) < win.span)) {    // outside the window: everything the long way
-        const float ilen = 0x42000000p0f / dot;
-        const float ilen2 = ilen + ilen;
-        round_slow((r.dx * invx) * ilen2, (r.dy * invy) * ilen2, (r.dz * invz) * ilen2);
+        const float ilen = 0x42000000p0f / dot;             // NaN / inf / out of range: x86 cvttss2si semantics
+        r.px += (uint32_t)round_to_i32((r.dx * invx) * ilen);
+        r.py += (uint32_t)round_to_i32((r.dy * invy) * ilen);
+        r.pz += (uint32_t)round_to_i32((r.dz * invz) * ilen);
         return false;
     }
-    const float ilen2 = ilen2_short(dot);                   // == 2 * (0x42000000p0f / dot), proven exhaustively
-    r.px += round_half_i32((r.dx * invx) * ilen2);          // |t| < 2^31 inside the window (StepWindow, condition 2)
-    r.py += round_half_i32((r.dy * invy) * ilen2);
-    r.pz += round_half_i32((r.dz * invz) * ilen2);
+    const float ilen = ilen_short(dot);                     // == 0x42000000p0f / dot, proven exhaustively
+    r.px = add_round(r.px, (r.dx * invx) * ilen);           // |s| < 2^30 inside the window (StepWindow, condition 2)
+    r.py = add_round(r.py, (r.dy * invy) * ilen);
+    r.pz = add_round(r.pz, (r.dz * invz) * ilen);
     return false;
 }
 
@@ -235,17 +240,16 @@ __device__ __forceinline__ void march_step_now(Ray &r, const f4 (&c)[8], const W
     else { r.dx = fma_(g[0], invx, r.dx); r.dy = fma_(g[1], invy, r.dy); r.dz = fma_(g[2], invz, r.dz); }
     const float dot = fma_(r.dz, r.dz, fma_(r.dx, r.dx, r.dy * r.dy));
     const float ex = UNIT_INV ? r.dx : r.dx * invx, ey = UNIT_INV ? r.dy : r.dy * invy, ez = UNIT_INV ? r.dz : r.dz * invz;
-    const float ilen2 = ilen2_short(dot);                   // garbage outside the window, replaced below
-    uint32_t sx = round_half_i32(ex * ilen2), sy = round_half_i32(ey * ilen2), sz = round_half_i32(ez * ilen2);
+    const float ilen = ilen_short(dot);                     // garbage outside the window, replaced below
+    uint32_t nx = add_round(r.px, ex * ilen), ny = add_round(r.py, ey * ilen), nz = add_round(r.pz, ez * ilen);
     const bool outside = WINDOW_TEST && !((__float_as_uint(dot) - win.lo) < win.span);
     if (outside) {                                          // rare: skipped by one scalar branch when no lane needs it
-        const float ilen = 0x42000000p0f / dot;
-        const float il2 = ilen + ilen;
-        sx = (uint32_t)round_to_i32((ex * il2) * 0.5f);
-        sy = (uint32_t)round_to_i32((ey * il2) * 0.5f);
-        sz = (uint32_t)round_to_i32((ez * il2) * 0.5f);
+        const float il = 0x42000000p0f / dot;
+        nx = r.px + (uint32_t)round_to_i32(ex * il);
+        ny = r.py + (uint32_t)round_to_i32(ey * il);
+        nz = r.pz + (uint32_t)round_to_i32(ez * il);
     }
-    r.px += sx; r.py += sy; r.pz += sz;
+    r.px = nx; r.py = ny; r.pz = nz;
 }
 
 __device__ __forceinline__ bool in_field(const Ray &r, uint32_t bx1, uint32_t by1, uint32_t bz1)

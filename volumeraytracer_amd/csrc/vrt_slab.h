@@ -72,6 +72,14 @@ __device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c)
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
     return d;
 }
+// a.hi16 * b + c with b < 2^16 (wave-uniform): the cell coordinate is the high half of a brick-relative position, so the
+// shift is folded into the multiply (v_mad_u32_u16 with op_sel on the first source)
+__device__ __forceinline__ uint32_t mad_hi16(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t d;
+    asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(d) : "v"(a), "s"(b), "v"(c));
+    return d;
+}
 // The persistent variant's group counter is bumped as straight-line, wave-uniform code: the atomic executes
 // in lane 0 only by narrowing EXEC inside the asm block (restored before it ends).  An `if (lane == 0)`
 // region around it made the compiler carry the divergence into the march that follows (lane 0 then
@@ -349,6 +357,18 @@ __device__ __forceinline__ void gather_lds(const LV *seg, uint32_t base, uint32_
     v[2] = b[sy];      v[3] = b[sy + 1];
     v[4] = b[sx];      v[5] = b[sx + 1];
     v[6] = b[sx + sy]; v[7] = b[sx + sy + 1];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cvt_vox(v[k], c[k]);
+}
+
+// the same from a byte address inside the wavefront's segment and byte strides (mad_hi16 builds the address)
+template <typename LV>
+__device__ __forceinline__ void gather_lds_at(uint32_t a0, uint32_t sy16, uint32_t sx16, f4 (&c)[8])
+{
+    const uint32_t a1 = a0 + sy16, a2 = a0 + sx16, a3 = a2 + sy16;
+    LV v[8];
+    v[0] = lds_at<LV>(a0)[0]; v[1] = lds_at<LV>(a0)[1]; v[2] = lds_at<LV>(a1)[0]; v[3] = lds_at<LV>(a1)[1];
+    v[4] = lds_at<LV>(a2)[0]; v[5] = lds_at<LV>(a2)[1]; v[6] = lds_at<LV>(a3)[0]; v[7] = lds_at<LV>(a3)[1];
 #pragma unroll
     for (int k = 0; k < 8; ++k) cvt_vox(v[k], c[k]);
 }
@@ -661,6 +681,8 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
             // the weights and every position update are unchanged): the cell is then one shift, not an SDWA subtract
             const uint32_t ox = lox << 16, oy = loy << 16, oz = loz << 16;
             r.px -= ox; r.py -= oy; r.pz -= oz;
+            // byte strides and base of the brick in LDS: a cell's address is three v_mad_u32_u16 on the positions' high halves
+            const uint32_t sy16 = sy * (uint32_t)sizeof(lvox), sx16 = sx * (uint32_t)sizeof(lvox), seg_addr = lds_addr(seg, 0);
             auto run = [&](auto has_w) {
                 constexpr bool kHasW = decltype(has_w)::value;
                 constexpr bool kDies = kHasW || ABSORB;              // a ray can stop inside the round for another reason
@@ -697,7 +719,6 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                         stat_add(p, kStatLdsWaveSteps, Kg);
                         VRT_TL(tl_lds += Kg);
                         if (pos0) {
-                            const uint32_t sy16 = sy * (uint32_t)sizeof(lvox), sx16 = sx * (uint32_t)sizeof(lvox);
                             auto proven = [&](auto window_test, auto unit_inv) {
                                 for (uint32_t k = 0; k < Kg; ++k) {
                                     // everything the eight reads need (four addresses) and everything that would otherwise be
@@ -705,7 +726,8 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                                     // reads issue back to back and nothing waits on a write-after-read of a load in flight
                                     // (issuing the reads before the weights, which then cover part of the LDS latency, was
                                     // measured too: the compiler then waits for all eight reads at once; +2 % on config 4)
-                                    uint32_t a0 = lds_addr(seg, mad24(mad24(r.px >> 16, ey, r.py >> 16), ez, r.pz >> 16));
+                                    // brick-relative cells are the positions' high halves; byte strides of a brick fit 16 bits
+                                    uint32_t a0 = mad_hi16(r.pz, (uint32_t)sizeof(lvox), mad_hi16(r.py, sy16, mad_hi16(r.px, sx16, seg_addr)));
                                     uint32_t a1 = a0 + sy16, a2 = a0 + sx16, a3 = a2 + sy16;
                                     Weights w = lerp_weights(r);
                                     asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(w.wrx), "+v"(w.wlx), "+v"(w.wry),
@@ -734,14 +756,15 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
 #endif
                 }
                 const uint64_t m_pos0 = lane_mask(pos0);
+                // brick-relative positions: "cell < extent - 1" is a compare of the position itself, the cell index never forms
+                const uint32_t ex1s = ex1 << 16, ey1s = ey1 << 16, ez1s = ez1 << 16;
                 for (int k = 0; k < Kr; ++k) {
-                    const uint32_t cx = r.px >> 16, cy = r.py >> 16, cz = r.pz >> 16;
-                    const bool inb = cx < ex1 && cy < ey1 && cz < ez1;   // cell and its +1 neighbours are staged
+                    const bool inb = r.px < ex1s && r.py < ey1s && r.pz < ez1s;   // cell and its +1 neighbours are staged
                     const bool pos = kDies ? it > 0 : pos0;
                     // wave-level tests on the compare masks themselves (scalar ALU): a ballot of a compound
                     // bool would be materialised through v_cndmask + v_cmp
                     const uint64_t m_pos = kDies ? lane_mask(it > 0) : m_pos0;
-                    const uint64_t m_inb = lane_mask(cx < ex1) & lane_mask(cy < ey1) & lane_mask(cz < ez1);
+                    const uint64_t m_inb = lane_mask(r.px < ex1s) & lane_mask(r.py < ey1s) & lane_mask(r.pz < ez1s);
                     if ((m_pos & ~m_inb) != 0ull) {                      // rare: some lane is outside the brick
                         // the brick is clipped to the field, so a ray that left the field is outside the brick too
                         // and simply stops marching; a ray still inside the field forces a new plan
@@ -763,7 +786,7 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                         if (dark) { rem_w = it; it = 0; }
                         else {
                             f4 c[8];
-                            gather_lds(seg, mad24(mad24(cx, ey, cy), ez, cz), sy, sx, c);
+                            gather_lds_at<lvox>(mad_hi16(r.pz, (uint32_t)sizeof(lvox), mad_hi16(r.py, sy16, mad_hi16(r.px, sx16, seg_addr))), sy16, sx16, c);
                             if constexpr (kHasW) {
                                 if (march_step<kPrescaled>(r, c, invx, invy, invz, win, true)) { rem_w = it; it = 0; } else --it;
                             } else {
