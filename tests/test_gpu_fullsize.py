@@ -128,3 +128,42 @@ def test_config4_tiled():
     assert np.array_equal(want["end_direction"].view(np.uint32).reshape(-1, 3), whole["end_direction_bits"].reshape(-1, 3)[idx])
     assert np.array_equal(want["end_iteration"], whole["end_iteration"][idx])
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fdt", [np.float32, np.int16])
+def test_wide_field_stages_through_64_bit_addresses(fdt):
+    """The slab kernel stages a brick through 32-bit byte offsets beside a scalar base whenever the widest brick of the
+    field spans less than 4 GiB (vrt_slab.h: off32) -- true for every BASELINE config.  A field whose x-slices are large
+    enough takes the other branch (64-bit address per voxel): 6 x 2900 x 2900 int16 / 6 x 1500 x 1400 fp32, random rays in
+    all directions against the oracle, both kernels."""
+    B = [6, 2900, 2900] if fdt == np.int16 else [6, 1500, 1400]
+    assert 160 * B[1] * B[2] * (8 if fdt == np.int16 else 16) >= 1 << 32
+    n = B[0] * B[1] * B[2]
+    rng = np.random.RandomState(5)
+    # smooth-ish field: a few plane waves, so that rays bend but bricks stay compact
+    y = np.arange(B[1], dtype=np.float32)[:, None]
+    z = np.arange(B[2], dtype=np.float32)[None, :]
+    d = []
+    for k in range(3):
+        plane = (np.sin(y * (0.011 + 0.003 * k)) * np.cos(z * (0.013 - 0.002 * k))).astype(np.float32)
+        vol = np.stack([plane * (1.0 + 0.1 * x) for x in range(B[0])]) * (40.0 if fdt == np.float32 else 60.0)
+        d.append((vol.astype(np.float32) if fdt == np.float32 else np.round(vol).astype(np.int16)).reshape(-1))
+    tc = np.full(n, 0xFFFFFFFF, np.uint32)
+    tc[rng.randint(0, n, 2000)] = 7                                  # a few opaque-ish voxels (w > 0 bricks)
+    m = 20000
+    pv = np.stack([rng.uniform(0.5, B[0] - 1.5, m), rng.uniform(1, B[1] - 2, m), rng.uniform(1, B[2] - 2, m)], axis=1)
+    sp = np.round(pv * 65536).astype(np.uint32).reshape(-1)
+    u = rng.randn(m, 3)
+    u[:, 0] *= 0.02                                                  # mostly along y / z: long paths inside the thin field
+    u /= np.linalg.norm(u, axis=1)[:, None]
+    sd = u.astype(np.float32).reshape(-1)
+    field = oracle.port.interleave(d[0], d[1], d[2], tc)
+    want = oracle.port.trace(field, B, sp, sd, [1, 1, 1], 4000)
+    assert want["end_iteration"].astype(np.int64).mean() > 200      # the rays really march
+    with capi.Engine.from_host(B, d, tc) as eng:
+        for kernel in (capi.KERNEL_SLAB, capi.KERNEL_DIRECT):
+            got = eng.trace(sp, sd, [1, 1, 1], 4000, options=capi.Options(kernel=kernel))
+            for k in ("end_position", "end_iteration", "remaining_light"):
+                assert np.array_equal(got[k], want[k]), (k, kernel)
+            assert np.array_equal(got["end_direction"].view(np.uint32), want["end_direction"].view(np.uint32)), kernel

@@ -164,6 +164,7 @@ struct vrt_engine {
     int num_cu = 256;
     float gmax[3] = {INFINITY, INFINITY, INFINITY};   // max |field channel| over the whole field (proven rounds, vrt_slab.h: safe_steps)
     float gnorm = INFINITY;                            // >= max over the field of the gradient vector's length
+    uint32_t field_flags = 0;                          // vrt::kFieldPrescaleOk once the field scan has shown it (engine_field_absmax)
     DevBuf transl;                 // translucency per field voxel, kept only for the opt-in absorption mode
     Workspace ws[kLanes];
     std::mutex mu;                 // device-pointer calls: one host thread at a time inside an engine
@@ -225,19 +226,24 @@ int launch_interleave(vrt_engine *e, const void *const d_diff[3], const uint32_t
 // Non-negative floats order like their bit patterns, and a NaN's pattern is above infinity's: an atomic max on the
 // patterns of |v| returns the largest magnitude, or a NaN if the field holds one (which then disables proven rounds).
 template <typename VoxT>
-__global__ __launch_bounds__(256) void k_field_absmax(const VoxT *f, size_t n, uint32_t *out /* [4]: |x|, |y|, |z|, x^2+y^2+z^2 */)
+__global__ __launch_bounds__(256) void k_field_absmax(const VoxT *f, size_t n, uint32_t *out /* [5]: |x|, |y|, |z|, x^2+y^2+z^2, ~(smallest non-zero |x|, |y| or |z|) */)
 {
-    uint32_t m[4] = {0u, 0u, 0u, 0u};
+    uint32_t m[5] = {0u, 0u, 0u, 0u, 0u};
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const VoxT v = f[i];
         const float a[3] = {(float)v.x, (float)v.y, (float)v.z};
 #pragma unroll
-        for (int d = 0; d < 3; ++d) { const uint32_t b = __float_as_uint(a[d]) & 0x7FFFFFFFu; m[d] = b > m[d] ? b : m[d]; }
+        for (int d = 0; d < 3; ++d) {
+            const uint32_t b = __float_as_uint(a[d]) & 0x7FFFFFFFu;
+            m[d] = b > m[d] ? b : m[d];
+            const uint32_t c = ~(b - 1u);                // complement of (b - 1): a zero wraps to the largest b - 1, i.e. the smallest c
+            m[4] = c > m[4] ? c : m[4];
+        }
         const uint32_t q = __float_as_uint(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]) & 0x7FFFFFFFu;   // squared length of the gradient vector
         m[3] = q > m[3] ? q : m[3];
     }
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
+    for (int d = 0; d < 5; ++d) {
         for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)m[d], o); m[d] = t > m[d] ? t : m[d]; }
         if ((threadIdx.x & 63u) == 0) atomicMax(&out[d], m[d]);
     }
@@ -245,7 +251,7 @@ __global__ __launch_bounds__(256) void k_field_absmax(const VoxT *f, size_t n, u
 
 int engine_field_absmax(vrt_engine *e, hipStream_t s)
 {
-    uint32_t *d_out = nullptr, h[4] = {0, 0, 0, 0};
+    uint32_t *d_out = nullptr, h[5] = {0, 0, 0, 0, 0};
     HIP_TRY(hipMalloc(&d_out, sizeof h));
     hipError_t err = hipMemsetAsync(d_out, 0, sizeof h, s);
     if (err == hipSuccess) {
@@ -262,6 +268,10 @@ int engine_field_absmax(vrt_engine *e, hipStream_t s)
     float q;
     memcpy(&q, &h[3], 4);
     e->gnorm = (float)(std::sqrt((double)q) * (1.0 + 1.0 / 1024.0));     // >= the longest gradient vector (float sum of squares: 3 roundings)
+    // prescale_ok (vrt_slab.h) for the whole field at once: every non-zero |value| in [2^-55, 2^78), which also rules out
+    // NaN and infinity (their patterns are the largest); h[4] = ~(smallest non-zero pattern - 1), 0 for an all-zero field
+    const uint32_t hi = std::max(h[0], std::max(h[1], h[2])), lo = h[4] ? ~h[4] + 1u : 0x7F800000u;
+    e->field_flags = (e->field_type == VRT_I16 || (hi < ((127u + 78u) << 23) && lo >= ((127u - 55u) << 23))) ? vrt::kFieldPrescaleOk : 0u;
     return VRT_OK;
 }
 
@@ -417,6 +427,7 @@ int trace_device_impl(vrt_engine *e, Workspace &w, int dir_type, size_t nrays, c
     p.Bx = e->B[0]; p.By = e->B[1]; p.Bz = e->B[2];
     p.invx = invscale[0]; p.invy = invscale[1]; p.invz = invscale[2];
     step_window(invscale, &p.win_lo, &p.win_span);
+    p.field_flags = getenv("VRT_DEBUG_BRICK_TESTS") ? 0u : e->field_flags;   // (tests: force the per-brick prescale test)
     for (int d = 0; d < 3; ++d) {                        // upper bound of |g_d * inv_d| per step, rounded up (safe_steps)
         const double g = (double)e->gmax[d] * std::fabs((double)invscale[d]) * (1.0 + 1.0 / 1048576.0);
         float gf = (float)g;
@@ -870,6 +881,7 @@ int engine_replicate(vrt_engine *e)
         if (rc) return rc;
         memcpy(r->gmax, e->gmax, sizeof r->gmax);
         r->gnorm = e->gnorm;
+        r->field_flags = e->field_flags;
         hipStream_t s = r->ws[0].stream;
         if (r->device != e->device) {
             int can = 0;

@@ -47,10 +47,13 @@ struct MarchParams {
     uint32_t out_pos_bias;    // added to end_pos / path on output: 0 at the seam, 0x10000 for the scene
                               // layer's "+0x10000" epilogue (image_util.cpp:770-771)
     unsigned long long *clock_out; // optional: 4 words {s_memtime, s_memrealtime} x {begin, end} of one wavefront (wave 0 of block 0)
+    uint32_t field_flags;     // kFieldPrescaleOk: every voxel of the field passes prescale_ok (vrt_slab.h), bricks need no test
     float gstep_norm;         // slab kernel: upper bound of the LENGTH of the change of dir in one step (longest gradient vector x max |inv_d|)
     float gstep[3];           // slab kernel: upper bound of |g_d * inv_d|, the change of dir_d in one step (.cu:344-345):
                               // max |field channel d| over the whole field x |inv_d|, rounded up (see safe_steps, vrt_slab.h)
 };
+
+constexpr uint32_t kFieldPrescaleOk = 1u;
 
 struct f4 { float x, y, z, w; };
 

@@ -72,6 +72,20 @@ __device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c)
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
     return d;
 }
+// c - a * b for a, b, c < 2^23 (the remainder of a division: a = quotient, b = wave-uniform divisor) in one instruction
+__device__ __forceinline__ uint32_t nmad24(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(0u - b), "v"(c));
+    return d;
+}
+// (a * m) >> 22 for a < 2^10, m < 2^22 + 4 (stage_magic): the quotient a / d
+__device__ __forceinline__ uint32_t div22(uint32_t a, uint32_t m)
+{
+    uint32_t d;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(d) : "s"(m), "v"(a));
+    return d >> 22;
+}
 // a.hi16 * b + c with b < 2^16 (wave-uniform): the cell coordinate is the high half of a brick-relative position, so the
 // shift is folded into the multiply (v_mad_u32_u16 with op_sel on the first source)
 __device__ __forceinline__ uint32_t mad_hi16(uint32_t a, uint32_t b, uint32_t c)
@@ -291,6 +305,35 @@ __device__ __forceinline__ uint32_t safe_steps(const Ray &r /* relative to the b
     window_ok = ok && win.span != 0u && dot * 0.55f >= __uint_as_float(win.lo) && dot * 1.6f < __uint_as_float(win.lo + win.span - 1u);
     return (ok && inside && n >= 0.0f) ? steps : 1u;
 }
+
+// Staging: q = n / d for n < 2^10 and a wave-uniform 2 <= d <= 2^10 as (n * m) >> 22 with m = 2^22 / d + (0, 3]: exact
+// because n * (m - 2^22 / d) < 2^22 / d for every such pair (brute-forced on the host for every d, n and every float
+// evaluation error of m up to +-0.75; the rcp + multiply + add below err by less than 0.5), and n * m < 2^32.
+__device__ __forceinline__ uint32_t stage_magic(uint32_t d)
+{
+    return sgpr((uint32_t)(4194304.0f * __builtin_amdgcn_rcpf((float)d) + 2.0f));
+}
+// one voxel through a raw buffer descriptor over the brick's origin: scalar base + 32-bit byte offset per lane (no 64-bit
+// address arithmetic in vector registers)
+template <typename V> __device__ __forceinline__ V load_vox_buf(__amdgpu_buffer_rsrc_t rsrc, uint32_t off);
+template <> __device__ __forceinline__ vox_f32 load_vox_buf<vox_f32>(__amdgpu_buffer_rsrc_t rsrc, uint32_t off)
+{
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0);
+    vox_f32 v;
+    v.x = __uint_as_float(a.x); v.y = __uint_as_float(a.y); v.z = __uint_as_float(a.z); v.w = __uint_as_float(a.w);
+    return v;
+}
+template <> __device__ __forceinline__ vox_i16 load_vox_buf<vox_i16>(__amdgpu_buffer_rsrc_t rsrc, uint32_t off)
+{
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    const u2 a = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)off, 0, 0);
+    vox_i16 v;
+    v.x = (int16_t)(a.x & 0xFFFFu); v.y = (int16_t)(a.x >> 16); v.z = (int16_t)(a.y & 0xFFFFu); v.w = (int16_t)(a.y >> 16);
+    return v;
+}
+__device__ __forceinline__ int32_t w_bits(const vox_f32 &v) { return __float_as_int(v.w); }
+__device__ __forceinline__ int32_t w_bits(const vox_i16 &v) { return v.w; }
 
 // The LDS brick always holds fp32 voxels: an int16 field is converted once while it is staged
 // (exact: (float)int16), not 32 times per step.
@@ -539,39 +582,62 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
         bool staged = false;
         // ---- stage: brick -> LDS ----------------------------------------------------------
         if (!(vol > kCap || K < kSlabMinK || bk.e[0] < 2 || bk.e[1] < 2 || bk.e[2] < 2)) {
-            // exact division by the wave-uniform extents via 2^32 reciprocals (v < 2^16)
-            const uint32_t mz = (uint32_t)(0x100000000ull / ez) + 1u;     // ez >= 2
-            const uint32_t my = (uint32_t)(0x100000000ull / ey) + 1u;     // ey >= 2
-            const size_t gsy = p.Bz, gsx = (size_t)p.By * p.Bz;
+            // voxel v of the brick -> (lx, ly, lz): exact division of v < 2^10 by the wave-uniform extents through
+            // (v * m) >> 22, two full-rate instructions (stage_magic); the voxel's offset from the brick origin as a
+            // 32-bit byte offset beside a scalar base whenever the field is small enough for that (off32)
+            const uint32_t mz = stage_magic(ez), my = stage_magic(ey);
+            const uint32_t gsy = p.Bz, gsx = p.By * p.Bz;             // gsx is only used when off32 holds (then < 2^24)
             const vox *g0 = f + ((size_t)bk.lo[0] * p.By + bk.lo[1]) * p.Bz + bk.lo[2];
+            const bool off32 = (unsigned long long)(kCap / 4u) * p.By * p.Bz * sizeof(vox) < (1ull << 32);   // lx < kCap / 4
             vox tmp[VPL];
-#pragma unroll
-            for (int j = 0; j < VPL; ++j) {
-                const uint32_t v = lane + 64u * j;
-                const uint32_t vc = v < vol ? v : 0u;                 // clamp: lanes past the end re-read voxel 0
-                const uint32_t t = __umulhi(vc, mz);                  // vc / ez
-                const uint32_t lz = vc - t * ez;
-                const uint32_t lx = __umulhi(t, my);                  // t / ey
-                const uint32_t ly = t - lx * ey;
-                tmp[j] = g0[(size_t)lx * gsx + (size_t)ly * gsy + lz];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");    // previous round's LDS reads are done
-            bool wpos = false, tiny = false;
-#pragma unroll
-            for (int j = 0; j < VPL; ++j) {
-                wpos |= tmp[j].w > 0;                                 // lanes past the end re-read voxel 0: harmless
-                if constexpr (kPrescaled) tiny |= !prescale_ok(tmp[j]);
-            }
-            // fp32 bricks carry the interpolation's 2^-48 (three multiplications less per step); a brick holding a value
-            // too small for that to be exact (prescale_ok) is not staged at all: the round gathers from global memory
-            staged = !kPrescaled || !any_lane(tiny);
-            if (staged) {
+            const uint32_t vlast = vol - 1u;
+            if (off32) {
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)g0, 0, 0xFFFFFFFF, 0x00020000);   // raw, no stride
 #pragma unroll
                 for (int j = 0; j < VPL; ++j) {
                     const uint32_t v = lane + 64u * j;
-                    if (v < vol) seg[v] = to_lds_vox(tmp[j]);
+                    const uint32_t vc = v < vlast ? v : vlast;            // clamp: lanes past the end re-read the last voxel
+                    const uint32_t t = div22(vc, mz);                     // vc / ez
+                    const uint32_t lz = nmad24(t, ez, vc);
+                    const uint32_t lx = div22(t, my);                     // t / ey
+                    const uint32_t ly = nmad24(lx, ey, t);
+                    tmp[j] = load_vox_buf<vox>(rsrc, mad24(lx, gsx, mad24(ly, gsy, lz)) * (uint32_t)sizeof(vox));
                 }
-                brick_has_w = any_lane(wpos);                     // wave-uniform: any opaque-ish voxel staged?
+            } else {
+                const size_t gsy64 = p.Bz, gsx64 = (size_t)p.By * p.Bz;
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) {
+                    const uint32_t v = lane + 64u * j;
+                    const uint32_t vc = v < vlast ? v : vlast;
+                    const uint32_t t = div22(vc, mz);
+                    const uint32_t lz = nmad24(t, ez, vc);
+                    const uint32_t lx = div22(t, my);
+                    const uint32_t ly = nmad24(lx, ey, t);
+                    tmp[j] = g0[(size_t)lx * gsx64 + (size_t)ly * gsy64 + lz];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");    // previous round's LDS reads are done
+            // w > 0 somewhere in the brick: w values are integers (never NaN, never -0.0), so the sign test is an integer
+            // maximum of the bit patterns; lanes past the end re-read the last voxel: harmless
+            int32_t wmax = 0;
+            bool tiny = false;
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) wmax = max(wmax, w_bits(tmp[j]));
+            // fp32 bricks carry the interpolation's 2^-48 (three multiplications less per step); a brick holding a value
+            // too small for that to be exact (prescale_ok) is not staged at all: the round gathers from global memory.
+            // The engine scans the field once (engine_field_absmax): when every voxel of it passes, no brick is tested.
+            if constexpr (kPrescaled) {
+                if (!(p.field_flags & kFieldPrescaleOk)) {
+#pragma unroll
+                    for (int j = 0; j < VPL; ++j) tiny |= !prescale_ok(tmp[j]);
+                }
+            }
+            staged = !kPrescaled || !any_lane(tiny);
+            if (staged) {
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) seg[lane + 64u * j] = to_lds_vox(tmp[j]);   // past the brick's end: copies of its last
+                                                                                        // voxel into the segment's unused rest
+                brick_has_w = any_lane(wmax > 0);                 // wave-uniform: any opaque-ish voxel staged?
                 stat_add(p, kStatRounds, 1);
                 VRT_TL(++tl_rounds);
                 stat_add(p, kStatPlannedK, (unsigned long long)K);
