@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where do the slab kernel's wavefronts spend their cycles?  (development aid; needs tools/build_debug.sh)
 
-    VRT_LIB=$PWD/tmp_libs/libvrt_phases.so VRT_DEBUG_STATS=1 python3 tools/phases.py [--config 3]
+    VRT_LIB=$PWD/build/ab/libvrt_phases.so VRT_DEBUG_STATS=1 python3 tools/phases.py [--config 3]
 
 Prints, for one march launch of a bench config: the clock the kernel ran at (s_memtime / s_memrealtime), the share of
 wavefront lifetime spent planning / staging / marching out of LDS / marching out of global memory, and shader cycles

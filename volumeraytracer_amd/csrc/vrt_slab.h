@@ -695,8 +695,16 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
             // lanes that entered a new cell gather again (a quarter of the lanes per step -- the vector L1 / TA
             // path is what bounds this mode): -6 % on config 5.  An fp32 field needs 32 registers for that,
             // which spills at 6 waves/SIMD (+27 % on config 3), so it gathers every step.
-            constexpr bool kKeepCorners = sizeof(FieldT) == 2;   // (fp32 at 5 waves/SIMD and 96 registers still spills: 9.5 vs 9.0 ms)
+#ifdef VRT_NO_KEEP_F32
+            constexpr bool kKeepF32 = OCC < 0;
+#else
+            // at 4 waves/SIMD (128 registers) the eight CONVERTED corners (32 registers) stay live for either field type:
+            // config 3 (fp32 field) 8.15 -> 7.31 ms -- its global-gather rounds were 8 % of the steps but 16 % of a wavefront's life
+            constexpr bool kKeepF32 = OCC <= 4;
+#endif
+            constexpr bool kKeepCorners = !kKeepF32 && sizeof(FieldT) == 2;   // (fp32 at 5 waves/SIMD and 96 registers spills: 9.5 vs 9.0 ms)
             vox kept[kKeepCorners ? 8 : 1];
+            f4 keptf[kKeepF32 ? 8 : 1];
             uint32_t have_xy = 0xFFFFFFFFu, have_z = 0xFFFFFFFFu;   // cell of the corners in kept[]: (x | y << 16, z); none yet
             const int direct_steps = SLICED ? (int)(budget < (uint32_t)kSlabDirectSteps ? budget : (uint32_t)kSlabDirectSteps) : kSlabDirectSteps;
             for (int k = 0; k < direct_steps; ++k) {
@@ -710,20 +718,29 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                     if constexpr (ABSORB) dark = absorb_step(p, r, light);
                     if (dark) { rem_w = it; it = 0; }
                     else {
-                        f4 c[8];
-                        if constexpr (kKeepCorners) {
-                            const uint32_t xy = (r.px >> 16) | (r.py & 0xFFFF0000u), z = r.pz >> 16;
+                        const uint32_t xy = (r.px >> 16) | (r.py & 0xFFFF0000u), z = r.pz >> 16;
+                        if constexpr (kKeepF32) {
                             if (xy != have_xy || z != have_z) {
-                                gather_global_raw<FieldT>(f, r, p.By, p.Bz, kept);
+                                gather_global<FieldT>(f, r, p.By, p.Bz, keptf);
                                 have_xy = xy;
                                 have_z = z;
                             }
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) cvt_vox(kept[q], c[q]);
+                            if (march_step(r, keptf, invx, invy, invz, win)) { rem_w = it; it = 0; } else --it;
                         } else {
-                            gather_global<FieldT>(f, r, p.By, p.Bz, c);
+                            f4 c[8];
+                            if constexpr (kKeepCorners) {
+                                if (xy != have_xy || z != have_z) {
+                                    gather_global_raw<FieldT>(f, r, p.By, p.Bz, kept);
+                                    have_xy = xy;
+                                    have_z = z;
+                                }
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) cvt_vox(kept[q], c[q]);
+                            } else {
+                                gather_global<FieldT>(f, r, p.By, p.Bz, c);
+                            }
+                            if (march_step(r, c, invx, invy, invz, win)) { rem_w = it; it = 0; } else --it;
                         }
-                        if (march_step(r, c, invx, invy, invz, win)) { rem_w = it; it = 0; } else --it;
                     }
                 }
             }
