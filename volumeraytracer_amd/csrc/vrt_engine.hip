@@ -1145,11 +1145,12 @@ static int scene_create_impl(vrt_scene_handle *out, int dim, const size_t *bound
             vrt::k_scene_build<<<grid, 256, 0, s>>>(vrt::SrcArray<int32_t>{(const int32_t *)d_lg}, vrt::SrcArray<uint32_t>{(const uint32_t *)d_tr},
                                                     sc->N[0], sc->N[1], sc->N[2], (vrt::vox_i16 *)e->field, derr, d_tc);
     }
-    if (hipGetLastError() != hipSuccess) return cleanup(fail(VRT_ERR_HIP, "scene build launch failed"));
+    if (const hipError_t le = hipGetLastError(); le != hipSuccess)
+        return cleanup(fail(VRT_ERR_HIP, "scene build launch failed: %s", hipGetErrorString(le)));
     vrt::SceneErr herr;
-    if (hipMemcpyAsync(&herr, d_err, sizeof herr, hipMemcpyDeviceToHost, s) != hipSuccess ||
-        hipStreamSynchronize(s) != hipSuccess)
-        return cleanup(fail(VRT_ERR_HIP, "scene build failed: %s", hipGetErrorString(hipGetLastError())));
+    hipError_t be = hipMemcpyAsync(&herr, d_err, sizeof herr, hipMemcpyDeviceToHost, s);
+    if (be == hipSuccess) be = hipStreamSynchronize(s);
+    if (be != hipSuccess) return cleanup(fail(VRT_ERR_HIP, "scene build failed: %s", hipGetErrorString(be)));
     if (herr.diff_overflow) return cleanup(fail(VRT_ERR_SCENE, "differention overflow"));          // image_util.cpp:291-293
     rc = engine_field_absmax(e, s);
     if (rc) return cleanup(rc);

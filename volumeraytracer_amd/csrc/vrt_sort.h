@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void k_wave_work(const typename FieldTraits<Fi
     est = max(est, (uint32_t)__shfl_xor((int)est, 1));
     est = max(est, (uint32_t)__shfl_xor((int)est, 2));
     if ((t & 3u) == 0) {
-        wkeys[w] = 0xFFFFFFFFu - (est >> VRT_LPT_SHIFT);                   // ascending sort = longest first
+        wkeys[w] = (uint32_t)kCoarseMaxLoops - (est >> VRT_LPT_SHIFT);     // ascending sort = longest first; est <= kCoarseMaxLoops: 12 key bits
         wvals[w] = w;
     }
 }
@@ -240,10 +240,12 @@ hipError_t build_tile_order(const uint32_t *d_pos, const void *d_dir, int dir_is
 #undef VRT_WW
         if ((e = hipGetLastError()) != hipSuccess) return e;
         size_t wtmp = 0;
-        e = rocprim::radix_sort_pairs(nullptr, wtmp, (const uint32_t *)wk, wk + nw, (const uint32_t *)wv, wv + nw, nw, 0, 32, s);
+        constexpr int kWaveKeyBits = 12;                   // keys are in [0, kCoarseMaxLoops = 2048]: two radix passes instead of four
+        static_assert(kCoarseMaxLoops < (1 << kWaveKeyBits), "wavefront sort key width");
+        e = rocprim::radix_sort_pairs(nullptr, wtmp, (const uint32_t *)wk, wk + nw, (const uint32_t *)wv, wv + nw, nw, 0, kWaveKeyBits, s);
         if (e != hipSuccess) return e;
         if (wtmp > tmp_bytes && (e = tmp.reserve(wtmp)) != hipSuccess) return e;
-        e = rocprim::radix_sort_pairs(tmp.p, wtmp, (const uint32_t *)wk, wk + nw, (const uint32_t *)wv, wv + nw, nw, 0, 32, s);
+        e = rocprim::radix_sort_pairs(tmp.p, wtmp, (const uint32_t *)wk, wk + nw, (const uint32_t *)wv, wv + nw, nw, 0, kWaveKeyBits, s);
         if (e != hipSuccess) return e;
         *wave_order_out = wv + nw;
     }
