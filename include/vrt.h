@@ -192,6 +192,10 @@ int vrt_selftest_ilen2(int device, unsigned long long *mismatches, unsigned long
  * every float with |s| < 2^31 against std::round + the x86 conversion.  *mismatches must come back 0;
  * *checked = 2 x 158 x 2^23 patterns. */
 int vrt_selftest_round(int device, unsigned long long *mismatches, unsigned long long *checked);
+/* Exhaustive device self-test of the integer division by multiplication with which the slab kernel splits a brick's voxel
+ * number into coordinates while staging: every divisor 2..1024 with every dividend below 1024, quotient and remainder.
+ * *mismatches must come back 0; *checked = 1023 x 1024. */
+int vrt_selftest_stage_division(int device, unsigned long long *mismatches, unsigned long long *checked);
 
 /* ---------------------------------------------------------------------------------------------
  * Scene layer: the reference's RaytraceScene<Ior,IorLog,Diff>

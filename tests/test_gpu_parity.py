@@ -317,6 +317,15 @@ def test_position_update_is_exact_for_every_step_below_2_31():
 
 
 @pytest.mark.gpu
+def test_staging_division_by_multiplication_is_exact():
+    """Staging splits a brick's voxel number v < 1024 into (x, y, z) by (v * m) >> 22 with m from a float reciprocal
+    (vrt_slab.h: stage_magic): the device checks quotient and remainder for every divisor 2..1024 and every dividend."""
+    bad, checked = capi.selftest_stage_division(0)
+    assert bad == 0
+    assert checked == 1023 * 1024
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fdt", [np.float32, np.int16])
 @pytest.mark.parametrize("ddt", [np.float32, np.int16])
 def test_persistent_schedule(fdt, ddt):

@@ -18,7 +18,7 @@ KERNEL_AUTO, KERNEL_DIRECT, KERNEL_SLAB = 0, 1, 2
 ABI_SYMBOLS = (
     "vrt_options_default", "vrt_device_count", "vrt_abi_version", "vrt_create", "vrt_create_from_device",
     "vrt_trace", "vrt_trace_device", "vrt_destroy", "vrt_engine_device", "vrt_engine_field_bytes",
-    "vrt_engine_field_device_ptr", "vrt_engine_last_march_ms", "vrt_engine_debug_stats", "vrt_selftest_ilen2", "vrt_selftest_round",
+    "vrt_engine_field_device_ptr", "vrt_engine_last_march_ms", "vrt_engine_debug_stats", "vrt_selftest_ilen2", "vrt_selftest_round", "vrt_selftest_stage_division",
     "vrt_last_error", "vrt_scene_create", "vrt_scene_create_lut", "vrt_scene_trace", "vrt_scene_destroy", "vrt_scene_engine",
     "vrt_engine_last_march_clock_ghz", "vrt_engine_replica_count", "vrt_debug_band_cut", "vrt_scene_trace_device",
     "vrt_scene_trace_status",
@@ -151,6 +151,15 @@ def selftest_round(device=0):
     L = load()
     L.vrt_selftest_round.argtypes = [C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     check(L.vrt_selftest_round(int(device), C.byref(bad), C.byref(n)))
+    return int(bad.value), int(n.value)
+
+
+def selftest_stage_division(device=0):
+    """Exhaustive device check of the staging loop's division by multiplication -> (mismatches, checked pairs)."""
+    bad, n = C.c_ulonglong(0), C.c_ulonglong(0)
+    L = load()
+    L.vrt_selftest_stage_division.argtypes = [C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    check(L.vrt_selftest_stage_division(int(device), C.byref(bad), C.byref(n)))
     return int(bad.value), int(n.value)
 
 

@@ -843,6 +843,23 @@ __global__ __launch_bounds__(256) void k_selftest_round(unsigned long long *out 
     if ((threadIdx.x & 63u) == 0) { atomicAdd(&out[0], bad); atomicAdd(&out[1], n); }
 }
 
+// Exhaustive self-test of the staging loop's division by multiplication (vrt_slab.h: stage_magic / div22 / nmad24): every
+// divisor 2 <= d <= 1024 (one per block) with every dividend n < 1024 against the integer quotient and remainder.
+__global__ __launch_bounds__(256) void k_selftest_stage_division(unsigned long long *out /* [2]: mismatches, checked */)
+{
+    const uint32_t d = blockIdx.x + 2u;
+    const uint32_t m = vrt::stage_magic(d);
+    unsigned long long bad = 0, n_checked = 0;
+    for (uint32_t n = threadIdx.x; n < 1024u; n += blockDim.x) {
+        const uint32_t q = vrt::div22(n, m), r = vrt::nmad24(q, d, n);
+        bad += q != n / d;
+        bad += r != n % d;
+        ++n_checked;
+    }
+    for (int o = 32; o > 0; o >>= 1) { bad += __shfl_xor(bad, o); n_checked += __shfl_xor(n_checked, o); }
+    if ((threadIdx.x & 63u) == 0) { atomicAdd(&out[0], bad); atomicAdd(&out[1], n_checked); }
+}
+
 // Devices a new handle spans: vrt_options.devices is a bit mask of HIP ordinals (0 = just vrt_options.device, -1 = every
 // visible device).  The first device of the list owns the handle's primary engine.  VRT_DEBUG_REPLICAS=n (tests on a
 // one-GPU box) makes n engines on the primary device instead, so that the band cut and the merge run without peers.
@@ -1412,6 +1429,24 @@ int vrt_selftest_round(int device, unsigned long long *mismatches, unsigned long
     HIP_TRY(hipMalloc(&d_out, sizeof(h_out)));
     hipError_t e = hipMemset(d_out, 0, sizeof(h_out));
     if (e == hipSuccess) { k_selftest_round<<<512, 256>>>(d_out); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(h_out, d_out, sizeof(h_out), hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);
+    HIP_TRY(e);
+    *mismatches = h_out[0];
+    *checked = h_out[1];
+    return VRT_OK;
+}
+
+int vrt_selftest_stage_division(int device, unsigned long long *mismatches, unsigned long long *checked)
+{
+    if (!mismatches || !checked) return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_selftest_stage_division: null output");
+    DeviceGuard g(device);
+    if (!g.ok) return fail(VRT_ERR_NO_DEVICE, "vrt_selftest_stage_division: cannot select device");
+    unsigned long long *d_out = nullptr, h_out[2] = {0, 0};
+    HIP_TRY(hipMalloc(&d_out, sizeof(h_out)));
+    hipError_t e = hipMemset(d_out, 0, sizeof(h_out));
+    if (e == hipSuccess) { k_selftest_stage_division<<<1023, 256>>>(d_out); e = hipGetLastError(); }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(h_out, d_out, sizeof(h_out), hipMemcpyDeviceToHost);
     (void)hipFree(d_out);
