@@ -46,6 +46,27 @@ def main():
         dev_ms = (time.perf_counter() - t0) * 1e3
     print("device-resident call (ray order + march): %.2f ms (march kernel %.2f ms)" % (dev_ms, eng.last_march_ms()))
     ref = o[2].cpu().numpy().view(np.uint32)
+    # the floor: the same bytes as bare copies (24 MB up, 32 MB down), from pageable and from pinned host memory
+    for pinned in (False, True):
+        h_up = [torch.from_numpy(sp.view(np.int32)), torch.from_numpy(sd)]
+        h_dn = [torch.empty_like(x, device="cpu") for x in o]
+        if pinned:
+            h_up = [x.pin_memory() for x in h_up]
+            h_dn = [x.pin_memory() for x in h_dn]
+        best_up = best_dn = 1e9
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            d_sp.copy_(h_up[0], non_blocking=True); d_sd.copy_(h_up[1], non_blocking=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for hx, dx in zip(h_dn, o):
+                hx.copy_(dx, non_blocking=True)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            best_up, best_dn = min(best_up, (t1 - t0) * 1e3), min(best_dn, (t2 - t1) * 1e3)
+        print("bare copies, %s host memory: up %.2f ms (%.1f GB/s), down %.2f ms (%.1f GB/s)" %
+              ("pinned" if pinned else "pageable", best_up, 24 * n / 1e6 / best_up, best_dn, 32 * n / 1e6 / best_dn))
     for lanes in (1, 2, 4, 8, 0):
         opts = capi.default_options(host_lanes=lanes)
         best = 1e9
