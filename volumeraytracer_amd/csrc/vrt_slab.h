@@ -691,18 +691,18 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
             __builtin_amdgcn_s_setprio(VRT_PRIO_DIRECT);
 #endif
             // A ray advances about a quarter voxel per step, so it reads the same eight corners for several
-            // steps in a row.  With an int16 field the raw corners (16 registers) stay in registers and only
-            // lanes that entered a new cell gather again (a quarter of the lanes per step -- the vector L1 / TA
-            // path is what bounds this mode): -6 % on config 5.  An fp32 field needs 32 registers for that,
-            // which spills at 6 waves/SIMD (+27 % on config 3), so it gathers every step.
+            // steps in a row: the corners stay in registers and only lanes that entered a new cell gather again
+            // (a quarter of the lanes per step).  At 4 waves/SIMD (128 registers) the eight CONVERTED corners
+            // (32 registers) stay live for either field type: config 3 (fp32 field) 8.15 -> 7.31 ms -- its global-gather
+            // rounds were 8 % of the steps but 16 % of a wavefront's life.  With fewer registers (6 waves/SIMD, 80)
+            // only an int16 field's RAW corners (16 registers) fit (-6 % on config 5 in round 1); fp32 corners spill
+            // there (+27 % on config 3, and still at 5 waves/SIMD with 96 registers), so that case gathers every step.
 #ifdef VRT_NO_KEEP_F32
-            constexpr bool kKeepF32 = OCC < 0;
+            constexpr bool kKeepF32 = OCC < 0;                  // (development: A/B)
 #else
-            // at 4 waves/SIMD (128 registers) the eight CONVERTED corners (32 registers) stay live for either field type:
-            // config 3 (fp32 field) 8.15 -> 7.31 ms -- its global-gather rounds were 8 % of the steps but 16 % of a wavefront's life
             constexpr bool kKeepF32 = OCC <= 4;
 #endif
-            constexpr bool kKeepCorners = !kKeepF32 && sizeof(FieldT) == 2;   // (fp32 at 5 waves/SIMD and 96 registers spills: 9.5 vs 9.0 ms)
+            constexpr bool kKeepCorners = !kKeepF32 && sizeof(FieldT) == 2;
             vox kept[kKeepCorners ? 8 : 1];
             f4 keptf[kKeepF32 ? 8 : 1];
             uint32_t have_xy = 0xFFFFFFFFu, have_z = 0xFFFFFFFFu;   // cell of the corners in kept[]: (x | y << 16, z); none yet
