@@ -129,10 +129,10 @@ __device__ __forceinline__ void cvt_vox(const vox_i16 &v, f4 &o)
 // Fast-path window of dot = |dir|^2, as float bit patterns: the step takes the short division and the integer
 // rounding iff (bits(dot) - lo) < span (unsigned; NaN, inf, negative values wrap out).  Two conditions are folded into it:
 //   (1) the exhaustively verified range of the short division, biased exponents 32..250 (div_window);
-//   (2) |t| < 2^31 for the three step components t_d = (dir_d * inv_d) * (2C / dot), which the integer rounding
-//       needs: |dir_d| <= sqrt(dot), so |t_d| <= 2C * max|inv| / sqrt(dot) < 2^31  <=>  dot > (2C * max|inv| / 2^31)^2.
+//   (2) |s| < 2^30 for the three step components s_d = (dir_d * inv_d) * (C / dot), inside the range add_round is exact
+//       on (|s| < 2^31): |dir_d| <= sqrt(dot), so 2 |s_d| <= 2C * max|inv| / sqrt(dot) < 2^31  <=>  dot > (2C * max|inv| / 2^31)^2.
 //       The host (step_window) rounds that bound up by 2^-16, far more than the few 2^-24 the float evaluation of
-//       dot, 2C/dot and the two products can add, so no per-step range test remains.
+//       dot, C/dot and the two products can add, so no per-step range test remains.
 struct StepWindow { uint32_t lo, span; };
 
 struct Ray {
