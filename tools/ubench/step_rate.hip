@@ -5,6 +5,8 @@
 //   MODE 0  step + in-brick test (the slab kernel's loop body)
 //   MODE 1  step without the in-brick test
 //   MODE 2  step on corners held in registers (no LDS reads): the pure VALU cost
+//   MODE 3  the production PROVEN loop body (vrt_slab.h): address by v_mad_u32_u16, eight ds_read_b128 from a prescaled brick,
+//           march_step_now without window test, unit invscale -- 79 VALU instructions + the 3 of the fold-back below
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -o step_rate step_rate.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -55,6 +57,35 @@ __global__ __launch_bounds__(256, OCC) void k_step(const vox_f32 *src, uint32_t 
             gather_lds(seg, mad24(mad24(cx, ey, cy), ez, cz), sy, sx, c);
             (void)march_step(r, c, invx, invy, invz, win, false);
             --it;
+        } else if (MODE == 4 || MODE == 5) {   // scheduling variants of MODE 3: 4 = no pinning at all, 5 = addresses pinned, weights after the reads
+            const uint32_t sy16 = sy * 16u, sx16 = sx * 16u, seg_addr = lds_addr(seg, 0);
+            uint32_t a0 = mad_hi16(r.pz, 16u, mad_hi16(r.py, sy16, mad_hi16(r.px, sx16, seg_addr)));
+            uint32_t a1 = a0 + sy16, a2 = a0 + sx16, a3 = a2 + sy16;
+            if (MODE == 5) asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) :: "memory");
+            vox_f32 v[8];
+            v[0] = lds_at<vox_f32>(a0)[0]; v[1] = lds_at<vox_f32>(a0)[1]; v[2] = lds_at<vox_f32>(a1)[0]; v[3] = lds_at<vox_f32>(a1)[1];
+            v[4] = lds_at<vox_f32>(a2)[0]; v[5] = lds_at<vox_f32>(a2)[1]; v[6] = lds_at<vox_f32>(a3)[0]; v[7] = lds_at<vox_f32>(a3)[1];
+            Weights w = lerp_weights(r);
+            if (MODE == 5) asm volatile("" : "+v"(w.wrx), "+v"(w.wlx), "+v"(w.wry), "+v"(w.wly), "+v"(w.wrz), "+v"(w.wlz));
+            f4 c[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cvt_vox(v[q], c[q]);
+            march_step_now<true, false, true>(r, c, w, invx, invy, invz, win);
+            --it;
+        } else if (MODE == 3) {
+            const uint32_t sy16 = sy * 16u, sx16 = sx * 16u, seg_addr = lds_addr(seg, 0);
+            uint32_t a0 = mad_hi16(r.pz, 16u, mad_hi16(r.py, sy16, mad_hi16(r.px, sx16, seg_addr)));
+            uint32_t a1 = a0 + sy16, a2 = a0 + sx16, a3 = a2 + sy16;
+            Weights w = lerp_weights(r);
+            asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(w.wrx), "+v"(w.wlx), "+v"(w.wry), "+v"(w.wly), "+v"(w.wrz), "+v"(w.wlz) :: "memory");
+            vox_f32 v[8];
+            v[0] = lds_at<vox_f32>(a0)[0]; v[1] = lds_at<vox_f32>(a0)[1]; v[2] = lds_at<vox_f32>(a1)[0]; v[3] = lds_at<vox_f32>(a1)[1];
+            v[4] = lds_at<vox_f32>(a2)[0]; v[5] = lds_at<vox_f32>(a2)[1]; v[6] = lds_at<vox_f32>(a3)[0]; v[7] = lds_at<vox_f32>(a3)[1];
+            f4 c[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cvt_vox(v[q], c[q]);
+            march_step_now<true, false, true>(r, c, w, invx, invy, invz, win);
+            --it;
         } else {
             (void)march_step(r, creg, invx, invy, invz, win, false);
             --it;
@@ -101,6 +132,9 @@ int main()
     hipMemcpy(src, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     run<0, 1>("step+test (LDS)", src); run<0, 2>("step+test (LDS)", src); run<0, 3>("step+test (LDS)", src); run<0, 4>("step+test (LDS)", src); run<0, 5>("step+test (LDS)", src); run<0, 6>("step+test (LDS)", src);
     run<1, 1>("step (LDS)", src); run<1, 2>("step (LDS)", src); run<1, 3>("step (LDS)", src); run<1, 4>("step (LDS)", src); run<1, 5>("step (LDS)", src); run<1, 6>("step (LDS)", src);
+    run<3, 1>("proven loop body (LDS)", src); run<3, 2>("proven loop body (LDS)", src); run<3, 3>("proven loop body (LDS)", src); run<3, 4>("proven loop body (LDS)", src); run<3, 5>("proven loop body (LDS)", src); run<3, 6>("proven loop body (LDS)", src);
+    run<4, 2>("proven body, unpinned", src); run<4, 3>("proven body, unpinned", src); run<4, 4>("proven body, unpinned", src); run<4, 6>("proven body, unpinned", src);
+    run<5, 2>("proven body, reads first", src); run<5, 3>("proven body, reads first", src); run<5, 4>("proven body, reads first", src); run<5, 6>("proven body, reads first", src);
     run<2, 1>("step (registers)", src); run<2, 2>("step (registers)", src); run<2, 3>("step (registers)", src); run<2, 4>("step (registers)", src); run<2, 5>("step (registers)", src); run<2, 6>("step (registers)", src);
     return 0;
 }
