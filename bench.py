@@ -230,8 +230,22 @@ def roofline_object(args, cfg, dev, eng, ray_steps, kernel_ms, clocks, bytes_per
             out["traffic_source"] = "%s: %s" % (inp.get("profile"), inp.get("hbm_bytes_formula"))
             out["hbm_measured"] = {"achieved": inp["hbm_bytes"] / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": inp["hbm_bytes"] / t / 1e9 / HBM_PEAK_GBS, "counter": "FETCH_SIZE, WRITE_SIZE"}
+    elif inp and inp.get("ray_steps") and inp.get("valu_insts") and clock and args.kernel == "auto" and args.lds_bytes == 0 and args.sort == 0:
+        # another cut of the same config (a rank's band at N > 1): the profiled launch's counters scaled by the ray-steps of
+        # this launch -- an estimate, marked as one (instructions per ray-step vary by a few per cent between bands)
+        k = ray_steps / float(inp["ray_steps"])
+        out["inputs"] = {"file": src, "profile": inp.get("profile"), "kernel": inp.get("kernel"), "round": inp.get("round"),
+                         "note": "counters of the profiled launch of this config scaled by ray-steps (x %.4f): estimate" % k}
+        out["estimated"] = True
+        out["achieved"] = inp["valu_insts"] * k / t / 1e9
+        out["frac"] = out["achieved"] / out["peak"]
+        out["valu"] = {"insts_per_launch": inp["valu_insts"] * k, "insts_per_64_ray_steps": inp["valu_insts"] / (inp["ray_steps"] / 64.0),
+                       "counter": "SQ_INSTS_VALU (scaled)", "frac": out["frac"]}
+        if inp.get("hbm_bytes"):
+            out["traffic"] = inp["hbm_bytes"] * k
+            out["traffic_source"] = "%s: %s, scaled by ray-steps (estimate)" % (inp.get("profile"), inp.get("hbm_bytes_formula"))
     else:
-        out["inputs"] = {"file": src, "note": "no counter profile of exactly this workload: counter-derived fractions omitted"}
+        out["inputs"] = {"file": src, "note": "no counter profile of this config: counter-derived fractions omitted"}
     return out
 
 
