@@ -5,6 +5,8 @@
 //   MODE 0  step + in-brick test (the slab kernel's loop body)
 //   MODE 1  step without the in-brick test
 //   MODE 2  step on corners held in registers (no LDS reads): the pure VALU cost
+//   MODE 6  MODE 3 with TWO independent rays per lane in the same brick (two dependent chains interleaved): what 128-ray
+//           groups would cost per PAIR of wave-steps
 //   MODE 3  the production PROVEN loop body (vrt_slab.h): address by v_mad_u32_u16, eight ds_read_b128 from a prescaled brick,
 //           march_step_now without window test, unit invscale -- 79 VALU instructions + the 3 of the fold-back below
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -o step_rate step_rate.hip
@@ -38,8 +40,33 @@ __global__ __launch_bounds__(256, OCC) void k_step(const vox_f32 *src, uint32_t 
     if (MODE == 2) gather_lds(seg, 60, ez, ey * ez, creg);
     const uint32_t sy = ez, sx = ey * ez;
     const uint64_t m_pos0 = lane_mask(it > 0);
+    Ray r2 = r;
+    r2.px += 0x4000u; r2.py += 0x2000u; r2.dy = -r.dy;
     for (int k = 0; k < nsteps; ++k) {
         const uint32_t cx = r.px >> 16, cy = r.py >> 16, cz = r.pz >> 16;
+        if (MODE == 6) {
+            const uint32_t sy16 = sy * 16u, sx16 = sx * 16u, seg_addr = lds_addr(seg, 0);
+            uint32_t a0 = mad_hi16(r.pz, 16u, mad_hi16(r.py, sy16, mad_hi16(r.px, sx16, seg_addr)));
+            uint32_t a1 = a0 + sy16, a2 = a0 + sx16, a3 = a2 + sy16;
+            uint32_t b0 = mad_hi16(r2.pz, 16u, mad_hi16(r2.py, sy16, mad_hi16(r2.px, sx16, seg_addr)));
+            uint32_t b1 = b0 + sy16, b2 = b0 + sx16, b3 = b2 + sy16;
+            Weights w = lerp_weights(r), w2 = lerp_weights(r2);
+            asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3) :: "memory");
+            vox_f32 v[8], u[8];
+            v[0] = lds_at<vox_f32>(a0)[0]; v[1] = lds_at<vox_f32>(a0)[1]; v[2] = lds_at<vox_f32>(a1)[0]; v[3] = lds_at<vox_f32>(a1)[1];
+            v[4] = lds_at<vox_f32>(a2)[0]; v[5] = lds_at<vox_f32>(a2)[1]; v[6] = lds_at<vox_f32>(a3)[0]; v[7] = lds_at<vox_f32>(a3)[1];
+            u[0] = lds_at<vox_f32>(b0)[0]; u[1] = lds_at<vox_f32>(b0)[1]; u[2] = lds_at<vox_f32>(b1)[0]; u[3] = lds_at<vox_f32>(b1)[1];
+            u[4] = lds_at<vox_f32>(b2)[0]; u[5] = lds_at<vox_f32>(b2)[1]; u[6] = lds_at<vox_f32>(b3)[0]; u[7] = lds_at<vox_f32>(b3)[1];
+            f4 c[8], e[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { cvt_vox(v[q], c[q]); cvt_vox(u[q], e[q]); }
+            march_step_now<true, false, true>(r, c, w, invx, invy, invz, win);
+            march_step_now<true, false, true>(r2, e, w2, invx, invy, invz, win);
+            --it;
+            r.px = (r.px & 0x1FFFFu) | 0x10000u; r.py = (r.py & 0x1FFFFu) | 0x10000u; r.pz = (r.pz & 0x1FFFFu) | 0x10000u;
+            r2.px = (r2.px & 0x1FFFFu) | 0x10000u; r2.py = (r2.py & 0x1FFFFu) | 0x10000u; r2.pz = (r2.pz & 0x1FFFFu) | 0x10000u;
+            continue;
+        }
         if (MODE == 0) {
             const uint64_t m_inb = lane_mask(cx < ex1) & lane_mask(cy < ey1) & lane_mask(cz < ez1);
             if ((m_pos0 & ~m_inb) != 0ull) {
@@ -94,7 +121,8 @@ __global__ __launch_bounds__(256, OCC) void k_step(const vox_f32 *src, uint32_t 
         r.px = (r.px & 0x1FFFFu) | 0x10000u; r.py = (r.py & 0x1FFFFu) | 0x10000u; r.pz = (r.pz & 0x1FFFFu) | 0x10000u;
     }
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) :: "memory");
-    out[blockIdx.x * blockDim.x + threadIdx.x] = r.px + r.py + r.pz + it + __float_as_uint(r.dx + r.dy + r.dz);
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r.px + r.py + r.pz + it + __float_as_uint(r.dx + r.dy + r.dz) +
+                                                 (MODE == 6 ? r2.px + r2.py + r2.pz + __float_as_uint(r2.dx + r2.dy + r2.dz) : 0u);
     if (lane == 0) { atomicAdd(clk, t1 - t0); atomicAdd(clk + 1, r1 - r0); }
 }
 
@@ -135,6 +163,7 @@ int main()
     run<3, 1>("proven loop body (LDS)", src); run<3, 2>("proven loop body (LDS)", src); run<3, 3>("proven loop body (LDS)", src); run<3, 4>("proven loop body (LDS)", src); run<3, 5>("proven loop body (LDS)", src); run<3, 6>("proven loop body (LDS)", src);
     run<4, 2>("proven body, unpinned", src); run<4, 3>("proven body, unpinned", src); run<4, 4>("proven body, unpinned", src); run<4, 6>("proven body, unpinned", src);
     run<5, 2>("proven body, reads first", src); run<5, 3>("proven body, reads first", src); run<5, 4>("proven body, reads first", src); run<5, 6>("proven body, reads first", src);
+    run<6, 1>("two rays per lane (per PAIR)", src); run<6, 2>("two rays per lane (per PAIR)", src); run<6, 3>("two rays per lane (per PAIR)", src); run<6, 4>("two rays per lane (per PAIR)", src);
     run<2, 1>("step (registers)", src); run<2, 2>("step (registers)", src); run<2, 3>("step (registers)", src); run<2, 4>("step (registers)", src); run<2, 5>("step (registers)", src); run<2, 6>("step (registers)", src);
     return 0;
 }
