@@ -547,6 +547,7 @@ int trace_device_impl(vrt_engine *e, Workspace &w, int dir_type, size_t nrays, c
             }
         }
         p.park = nullptr; p.slice_flags = nullptr; p.slice_steps = 0; p.ticket_limit = 0;
+        p.work_sum = nullptr; p.work_unit = (uint32_t)vrt::kCoarse; p.slice_percent = 115;
         if (schedule >= 2 && kernel == VRT_KERNEL_SLAB && groups > 1 && geo.complete) {
             HIP_TRY(w.group_ctr.reserve(4 * sizeof(uint32_t)));
             HIP_TRY(hipMemsetAsync(w.group_ctr.p, 0, 4 * sizeof(uint32_t), s));
@@ -554,8 +555,12 @@ int trace_device_impl(vrt_engine *e, Workspace &w, int dir_type, size_t nrays, c
             tuner_trial = trial;
             if (schedule == 3 && !p.transl) {
                 // time-sliced: parked state and per-group slice flags (vrt_slab.h, SCHED == 2)
-                uint32_t slice = 1024;
+                // slice length: derived in the kernel from the pre-march's work estimates when the launch has them (the wavefront
+                // launch order was built), else 1024 wave-steps; VRT_SLICE_STEPS / VRT_SLICE_PERCENT override (development)
+                uint32_t slice = p.wave_order ? 0u : 1024u;
                 if (const char *ev = getenv("VRT_SLICE_STEPS")) slice = (uint32_t)std::max(16L, strtol(ev, nullptr, 10));
+                if (const char *ev = getenv("VRT_SLICE_PERCENT")) p.slice_percent = (uint32_t)std::max(10L, strtol(ev, nullptr, 10));
+                if (p.wave_order) p.work_sum = &((const vrt::RayBounds *)w.sort_bounds.p)->work_sum;
                 // ring of re-queued groups: a power of two >= 2 x groups (at most one word per group is ever occupied)
                 unsigned long long cap = 64;
                 while (cap < 2ull * groups) cap <<= 1;

@@ -42,7 +42,11 @@ struct MarchParams {
                               // time-sliced schedule: [0] items drawn, [1] groups finished, [2] error word, [3] items appended
     void *park;               // time-sliced schedule only: parked ray state, 2 KiB per group ([group][2][64 lanes] x 16 B)
     uint32_t *slice_flags;    // time-sliced schedule only: the FIFO of re-queued groups (group + 1; 0 = not written yet)
-    uint32_t slice_steps;     // time-sliced schedule only: wave-steps per slice
+    uint32_t slice_steps;     // time-sliced schedule only: wave-steps per slice; 0 = derived in the kernel from the mean work
+                              // estimate of the launch's wavefronts (work_sum, work_unit, slice_percent)
+    const unsigned long long *work_sum;   // sum over the launch's wavefronts of the pre-march's estimate (vrt_sort.h, k_wave_work), or null
+    uint32_t work_unit;       // fine steps per unit of that estimate (kCoarse)
+    uint32_t slice_percent;   // slice = mean estimated wave-steps per wavefront x this / 100
     uint32_t ticket_limit;    // time-sliced schedule only: words in the FIFO ring (a power of two >= 2 x groups)
     uint32_t out_pos_bias;    // added to end_pos / path on output: 0 at the seam, 0x10000 for the scene
                               // layer's "+0x10000" epilogue (image_util.cpp:770-771)

@@ -22,11 +22,13 @@ namespace vrt {
 
 struct RayBounds {          // filled on the device, consumed on the device: no host round trip
     uint32_t lo[3], hi[3];  // min / max start position per axis (16.16)
+    unsigned long long work_sum;   // k_wave_work: sum of the wavefronts' work estimates (coarse steps); read by the time-sliced march
 };
 
 __global__ void k_bounds_init(RayBounds *b)
 {
     if (threadIdx.x < 3) { b->lo[threadIdx.x] = 0xFFFFFFFFu; b->hi[threadIdx.x] = 0u; }
+    if (threadIdx.x == 3) b->work_sum = 0ull;
 }
 
 __global__ __launch_bounds__(256) void k_ray_bounds(const uint32_t *pos, uint32_t n, RayBounds *b)
@@ -148,13 +150,16 @@ template <typename FieldT, typename DirT>
 __global__ __launch_bounds__(256) void k_wave_work(const typename FieldTraits<FieldT>::vox *field, const uint32_t *pos,
                                                    const DirT *dir, const uint32_t *order, uint32_t n, uint32_t Bx,
                                                    uint32_t By, uint32_t Bz, float invx, float invy, float invz,
-                                                   uint32_t iterations, uint32_t *wkeys, uint32_t *wvals)
+                                                   uint32_t iterations, uint32_t *wkeys, uint32_t *wvals, RayBounds *rb)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t w = t >> 2, nw = (n + 63u) >> 6;
-    if (w >= nw) return;                                   // whole groups of 4 threads leave together
+    __shared__ uint32_t s_sum;
+    if (threadIdx.x == 0) s_sum = 0u;
+    __syncthreads();
+    const bool valid = w < nw;                             // (threads past the end idle through the loop: the block meets again below)
     const uint32_t rep[4] = {5u, 23u, 40u, 58u};
-    uint32_t slot = w * 64u + rep[t & 3u];
+    uint32_t slot = (valid ? w : nw - 1u) * 64u + rep[t & 3u];
     slot = slot < n ? slot : n - 1u;
     const uint32_t i = order ? order[slot] : slot;
     float px = (float)pos[3 * (size_t)i], py = (float)pos[3 * (size_t)i + 1], pz = (float)pos[3 * (size_t)i + 2];
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(256) void k_wave_work(const typename FieldTraits<Fi
     const uint32_t cap = iterations / kCoarse + 1u;
     const uint32_t loops_max = cap < (uint32_t)kCoarseMaxLoops ? cap : (uint32_t)kCoarseMaxLoops;
     const float m = (float)kCoarse;
-    bool alive = true;
+    bool alive = valid;
     uint32_t est = 0;                                     // coarse steps until the last representative stops
     for (uint32_t loops = 0; loops < loops_max; ++loops) {
         alive = alive && px >= 0.0f && py >= 0.0f && pz >= 0.0f && px < hx && py < hy && pz < hz;   // false on NaN
@@ -186,10 +191,13 @@ __global__ __launch_bounds__(256) void k_wave_work(const typename FieldTraits<Fi
     // planner would have to gather from global memory by 1.5 was tried and ordered no better.)
     est = max(est, (uint32_t)__shfl_xor((int)est, 1));
     est = max(est, (uint32_t)__shfl_xor((int)est, 2));
-    if ((t & 3u) == 0) {
+    if (valid && (t & 3u) == 0) {
         wkeys[w] = (uint32_t)kCoarseMaxLoops - (est >> VRT_LPT_SHIFT);     // ascending sort = longest first; est <= kCoarseMaxLoops: 12 key bits
         wvals[w] = w;
+        atomicAdd(&s_sum, est);                            // LDS: 64 adds per block, then one global atomic per block
     }
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&rb->work_sum, (unsigned long long)s_sum);
 }
 
 // grow-only device buffer interface expected from the caller (see DevBuf in vrt_engine.hip)
@@ -234,7 +242,7 @@ hipError_t build_tile_order(const uint32_t *d_pos, const void *d_dir, int dir_is
         using vf = const FieldTraits<float>::vox *;
         using vi = const FieldTraits<int16_t>::vox *;
 #define VRT_WW(FT, DT, FP) k_wave_work<FT, DT><<<wgrid, 256, 0, s>>>((FP)field, d_pos, (const DT *)d_dir, ord, n, Bx, By, Bz, \
-                                                                     inv[0], inv[1], inv[2], iterations, wk, wv)
+                                                                     inv[0], inv[1], inv[2], iterations, wk, wv, rb)
         if (field_is_i16) { if (dir_is_i16) VRT_WW(int16_t, int16_t, vi); else VRT_WW(int16_t, float, vi); }
         else              { if (dir_is_i16) VRT_WW(float, int16_t, vf);   else VRT_WW(float, float, vf); }
 #undef VRT_WW
