@@ -535,7 +535,7 @@ int trace_device_impl(vrt_engine *e, Workspace &w, int dir_type, size_t nrays, c
                     if (ready) {
                         t.ms[0] = std::min(ms[0], ms[2]);
                         t.ms[1] = std::min(ms[1], ms[3]);
-                        t.choice = t.ms[1] < 0.985f * t.ms[0] ? 3 : 2;
+                        t.choice = t.ms[1] < 0.99f * t.ms[0] ? 3 : 2;
                         t.state = 5;
                         schedule = t.choice;
                         if (o.loglevel < 0) printf("schedule tuned: whole groups %.3f ms, time-sliced %.3f ms -> %d\n", t.ms[0], t.ms[1], t.choice);
