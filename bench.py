@@ -21,8 +21,13 @@ Prints ONE JSON line on rank 0 (see DESIGN.md §Measurement for the definitions)
                      next to it: roofline.lds, roofline.hbm_measured (counter bytes) and roofline.hbm_algorithmic, the
                      contract's 128 B (fp32 field; 64 B int16) per ray-step figure, which exceeds the HBM peak because
                      the bytes are served from LDS -- reported, but not a bound
-  cpu_baseline     = the oracle (oracle/vrt_oracle.c, "port") or the real reference build
-                     (oracle/_ref, "reference") on a bounded sample of the same rays, same field
+  cpu_baseline     = the oracle (oracle/vrt_oracle.c, "port") on a bounded sample of the same rays, same field, with the
+                     GPU's results checked against it bit for bit; cpu_baseline.reference = the REAL reference CPU path
+                     (oracle/_ref/libvrt_ref.so, built from /root/reference/src in the build container) timed on a smaller
+                     sample in a child process, when that library is present and loads on this host
+  N > 1            = rank 0 checks an evenly strided sample of the GATHERED records against the oracle
+                     ("gathered_matches_oracle"; a mismatch exits non-zero) and reports every rank's band, kernel time
+                     and gather time ("ranks")
 """
 import argparse
 import json
@@ -50,6 +55,7 @@ CONFIGS = {
     # diagnostic variants (not BASELINE configs)
     6: dict(N=512, R=1024, gen="ortho", field="f32", name="512^3 fp32 field, 1024x1024 orthographic rays (diagnostic)"),
     7: dict(N=512, R=1448, gen="perspective", field="f32", name="512^3 fp32 field, 1448x1448 perspective rays (diagnostic)"),
+    8: dict(N=512, R=2048, gen="perspective", field="i16", name="512^3 int16 field, 2048x2048 perspective rays (diagnostic: dense rays on an int16 field)"),
     # small smoke-size config for quick checks
     0: dict(N=96, R=256, gen="perspective", field="f32", name="96^3 fp32 field, 256x256 perspective rays (smoke)"),
 }
@@ -186,6 +192,65 @@ def cpu_baseline(field_host, bounds, sp, sd, inv, iterations, gpu_out, budget_s,
     return res
 
 
+def reference_leg_child(path):
+    """Child process of reference_leg(): time the real reference build on the sample stored at `path` (npz), print JSON."""
+    import oracle
+    z = np.load(path)
+    if not oracle.ref.available():
+        print(json.dumps({"error": "oracle/_ref/libvrt_ref.so absent or not loadable"}))
+        return
+    t0 = time.time()
+    out = oracle.ref.seam_trace([int(b) for b in z["bounds"]], z["dx"], z["dy"], z["dz"], z["tc"], z["sp"], z["sd"], z["inv"], int(z["iterations"]))
+    dt = time.time() - t0
+    np.savez(path + ".out.npz", end_position=out["end_position"], end_direction=out["end_direction"], end_iteration=out["end_iteration"])
+    print(json.dumps({"seconds": dt, "ray_steps": int(out["end_iteration"].astype(np.int64).sum()),
+                      "threads": int(os.environ.get("OMP_NUM_THREADS", "0")) or os.cpu_count()}))
+
+
+def reference_leg(host, tc_host, bounds, sp, sd, inv, iterations, port_out_for, budget_s, log):
+    """The real reference CPU path (oracle/_ref, compiled from the reference's own sources by oracle/Makefile in the
+    build container) timed on this host.  It runs in a child process: the objects were built with the reference
+    Makefile's -march=native on another CPU, and an illegal instruction must not take the benchmark down.  Returns the
+    "reference" object for cpu_baseline, or None when the library is absent / does not run here."""
+    so = os.path.join(ROOT, "oracle", "_ref", "libvrt_ref.so")
+    if not os.path.exists(so):
+        return None
+    import subprocess
+    import tempfile
+    n = sp.size // 3
+    m = int(min(n, 20000))
+    idx = np.linspace(0, n - 1, m).astype(np.int64)
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    path = os.path.join(tmpdir, "vrt_ref_leg_%d.npz" % os.getpid())
+    try:
+        np.savez(path, bounds=np.asarray(bounds), dx=host[0], dy=host[1], dz=host[2], tc=tc_host, sp=sp.reshape(-1, 3)[idx].reshape(-1),
+                 sd=sd.reshape(-1, 3)[idx].reshape(-1), inv=np.asarray(inv, np.float32), iterations=iterations)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--reference-leg", path], stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=max(60.0, 20 * budget_s))
+        if r.returncode != 0:
+            log("reference leg: child exited with %d (%s)" % (r.returncode, r.stderr.strip()[-200:]))
+            return {"ran": False, "note": "oracle/_ref/libvrt_ref.so does not run on this host (child exit %d)" % r.returncode}
+        j = json.loads(r.stdout.strip().splitlines()[-1])
+        if "error" in j:
+            return {"ran": False, "note": j["error"]}
+        got = np.load(path + ".out.npz")
+        want = port_out_for(idx)
+        same = (np.array_equal(got["end_position"], want["end_position"]) and np.array_equal(got["end_iteration"], want["end_iteration"])
+                and np.array_equal(got["end_direction"].view(np.uint32), want["end_direction"].view(np.uint32)))
+        return {"ran": True, "value": j["ray_steps"] / j["seconds"], "unit": "ray-steps/s", "cores": j["threads"], "kind": "reference",
+                "sample": "%d of %d rays (evenly strided), %d ray-steps, %.2f s, the reference's own OpenMP loop" % (m, n, j["ray_steps"], j["seconds"]),
+                "matches_port_bit_exact": bool(same)}
+    except Exception as ex:                                        # never let the optional leg break the benchmark
+        log("reference leg failed:", ex)
+        return {"ran": False, "note": str(ex)[:200]}
+    finally:
+        for f in (path, path + ".out.npz"):
+            try:
+                os.remove(f)
+            except OSError:
+                pass
+
+
 def roofline_object(args, cfg, dev, eng, ray_steps, kernel_ms, clocks, bytes_per_step):
     """The march kernel against its binding resource (module docstring).  Counter-derived inputs come from
     profiles/roofline_inputs.json and are used only when that profile was taken on this very workload (same number of
@@ -200,12 +265,15 @@ def roofline_object(args, cfg, dev, eng, ray_steps, kernel_ms, clocks, bytes_per
         src = os.path.relpath(args.roofline_inputs, ROOT)
     except Exception:
         inp = None
-    same = bool(inp) and inp.get("ray_steps") == ray_steps and args.kernel == "auto" and args.lds_bytes == 0 and args.sort == 0
+    sched = eng.last_schedule() if hasattr(capi.load(), "vrt_engine_last_schedule") else None
+    # the counters depend on the schedule the launch used (park / resume, re-planning): only a profile of the same one counts
+    sched_ok = bool(inp) and (inp.get("schedule") is None or sched is None or inp.get("schedule") == sched)
+    same = bool(inp) and inp.get("ray_steps") == ray_steps and args.kernel == "auto" and args.lds_bytes == 0 and args.sort == 0 and sched_ok
     alg = ray_steps * bytes_per_step / t / 1e9
     out = {"bound": "valu-issue", "achieved": None, "peak": None, "unit": "Gwave-instr/s", "frac": None,
            "traffic": None, "traffic_source": None, "kernel_ms": kernel_ms, "clock_ghz": clock / 1e9 if clock else None,
            "clock_source": "s_memtime / s_memrealtime of one wavefront of the march kernel, this run",
-           "simds": simds,
+           "simds": simds, "schedule_observed": sched,
            "hbm_algorithmic": {"achieved": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / HBM_PEAK_GBS,
                                "bytes_per_ray_step": bytes_per_step,
                                "note": "SURVEY 8(d) figure; exceeds 1 because the gather is served from LDS, not HBM: not a bound"},
@@ -230,7 +298,7 @@ def roofline_object(args, cfg, dev, eng, ray_steps, kernel_ms, clocks, bytes_per
             out["traffic_source"] = "%s: %s" % (inp.get("profile"), inp.get("hbm_bytes_formula"))
             out["hbm_measured"] = {"achieved": inp["hbm_bytes"] / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": inp["hbm_bytes"] / t / 1e9 / HBM_PEAK_GBS, "counter": "FETCH_SIZE, WRITE_SIZE"}
-    elif inp and inp.get("ray_steps") and inp.get("valu_insts") and clock and args.kernel == "auto" and args.lds_bytes == 0 and args.sort == 0:
+    elif inp and inp.get("ray_steps") and inp.get("valu_insts") and clock and args.kernel == "auto" and args.lds_bytes == 0 and args.sort == 0 and sched_ok:
         # another cut of the same config (a rank's band at N > 1): the profiled launch's counters scaled by the ray-steps of
         # this launch -- an estimate, marked as one (instructions per ray-step vary by a few per cent between bands)
         k = ray_steps / float(inp["ray_steps"])
@@ -296,7 +364,13 @@ def main():
     ap.add_argument("--rehearse", action="store_true",
                     help="development: let several ranks share one GPU (local_rank %% device_count) to exercise the "
                          "multi-rank code path on a single-GPU box; timings are meaningless")
+    ap.add_argument("--verify-rays", type=int, default=4096,
+                    help="N > 1: rays of the gathered records (evenly strided over the whole job) rank 0 checks against the oracle; 0 disables")
+    ap.add_argument("--reference-leg", default=None, help=argparse.SUPPRESS)    # internal: child process of reference_leg()
     args = ap.parse_args()
+    if args.reference_leg:
+        reference_leg_child(args.reference_leg)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -417,6 +491,69 @@ def main():
         clock_ghz.append(eng.last_march_clock_ghz())
     torch.cuda.synchronize()
 
+    # a scheduler failure (a bounded wait of the time-sliced schedule that ran out) would have left rays unfinished:
+    # vrt_trace_status reports it for every device-pointer call issued so far
+    if hasattr(capi.load(), "vrt_trace_status"):
+        eng.status()
+    kavg_local = float(np.mean(kernel_ms))
+
+    # ---- N > 1: what was gathered is what the oracle computes ---------------------------------------------------------
+    ranks_info, gathered_ok, verify_note = None, None, None
+    if world > 1:
+        # one more step, synchronous and timed per rank: march, then the gather on its own
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        if pipe is not None:
+            b_ep, b_ed, b_ei, b_rl = D.record_views(pipe.buffer(), n)
+            eng.trace_device(capi.VRT_F32, n, d_sp.data_ptr(), d_sd.data_ptr(), b_ep.data_ptr(), b_ed.data_ptr(),
+                             b_ei.data_ptr(), b_rl.data_ptr(), inv, args.iterations, stream=stream, options=opts)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            pipe.launch()
+            records = pipe.finish()
+        else:
+            eng.trace_device(capi.VRT_F32, n, d_sp.data_ptr(), d_sd.data_ptr(), o_ep.data_ptr(), o_ed.data_ptr(),
+                             o_ei.data_ptr(), o_rl.data_ptr(), inv, args.iterations, stream=stream, options=opts)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            records = D.gather_records(out.to(cdev), counts, dst=0)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        mine = {"rank": rank, "rays": n, "band_rows": list(band) if band is not None else list(D.row_band(lattice_rows(cfg, world, scaling), rank, world)),
+                "ray_steps": int(o_ei.to(torch.int64).sum().item()) if pipe is None else int(b_ei.to(torch.int64).sum().item()),
+                "kernel_ms": kavg_local, "march_step_ms": (t1 - t0) * 1e3, "gather_ms": (t2 - t1) * 1e3,
+                "schedule": eng.last_schedule() if hasattr(capi.load(), "vrt_engine_last_schedule") else None}
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, mine)
+        if rank == 0 and args.verify_rays > 0:
+            import oracle
+            whole = D.assemble(records, counts)
+            pick = D.sample_gathered(counts, args.verify_rays)         # [(rank, local indices)] evenly strided over the whole job
+            if d is not None:
+                field_host = oracle.port.interleave(d[0].cpu().numpy(), d[1].cpu().numpy(), d[2].cpu().numpy(), tr.cpu().numpy().view(np.uint32))
+            else:
+                dens, lut_ior, lut_tr = lut_host
+                hx, hy, hz, tc_h, _ = oracle.port.scene_build([N, N, N], lut_ior[dens], lut_tr[dens])
+                field_host = oracle.port.interleave(hx, hy, hz, tc_h)
+            bad, checked, base = 0, 0, 0
+            for r, idx in pick:
+                if idx.size:
+                    rsp, rsd = make_rays(cfg, r, world, tuple(ranks_info[r]["band_rows"]), scaling=scaling)
+                    want = oracle.port.trace(field_host, bounds, rsp.reshape(-1, 3)[idx].reshape(-1), rsd.reshape(-1, 3)[idx].reshape(-1),
+                                             inv, args.iterations)
+                    g = base + idx
+                    ok = (np.array_equal(whole["end_position"].reshape(-1, 3)[g], want["end_position"].reshape(-1, 3))
+                          and np.array_equal(whole["end_direction_bits"].reshape(-1, 3)[g], want["end_direction"].view(np.uint32).reshape(-1, 3))
+                          and np.array_equal(whole["end_iteration"][g], want["end_iteration"])
+                          and np.array_equal(whole["remaining_light"][g], want["remaining_light"]))
+                    bad += 0 if ok else 1
+                    checked += int(idx.size)
+                base += counts[r]
+            gathered_ok = bad == 0
+            verify_note = "%d rays of the gathered records (evenly strided over %d ranks' bands) against the oracle, bit for bit" % (checked, world)
+            log("gathered records vs oracle:", "match" if gathered_ok else "MISMATCH in %d rank(s)" % bad, "(%s)" % verify_note)
+
     if os.environ.get("VRT_DEBUG_STATS") == "1" and rank == 0:
         try:
             log("slab debug stats:", eng.debug_stats())
@@ -436,7 +573,7 @@ def main():
         return
 
     bytes_per_step = 128 if cfg["field"] == "f32" else 64
-    kavg_ms = float(np.mean(kernel_ms))
+    kavg_ms = kavg_local
     roofline = roofline_object(args, cfg, dev, eng, steps_local, kavg_ms, [c for c in clock_ghz if c > 0], bytes_per_step)
     result = {
         "metric": "ray-steps/sec",
@@ -459,6 +596,10 @@ def main():
                    "rays_total": int(sum(counts))},
         "roofline": roofline,
     }
+    if world > 1:
+        result["ranks"] = ranks_info
+        result["gathered_matches_oracle"] = gathered_ok
+        result["gathered_check"] = verify_note
     if args.cpu_seconds > 0 and world == 1:                        # CPU baseline: rank 0 at N = 1 only
         import oracle
         if d is not None:
@@ -471,16 +612,24 @@ def main():
             host = [hx, hy, hz]
             log("CPU scene build (oracle, untimed for the baseline): %.1f s" % (time.time() - t0))
         field_host = oracle.port.interleave(host[0], host[1], host[2], tc_host)
-        del host
         gpu_out = dict(end_position=o_ep.cpu().numpy().view(np.uint32),
                        end_direction=o_ed.cpu().numpy().view(np.float32),
                        end_iteration=o_ei.cpu().numpy().view(np.uint32))
         result["cpu_baseline"] = cpu_baseline(field_host, bounds, sp, sd, inv, args.iterations, gpu_out,
                                               args.cpu_seconds, log)
+        if d is not None:                                          # the real reference build, when it travelled and runs here
+            sp3, sd3 = sp.reshape(-1, 3), sd.reshape(-1, 3)
+            ref = reference_leg(host, tc_host, bounds, sp, sd, inv, args.iterations,
+                                lambda idx: oracle.port.trace(field_host, bounds, sp3[idx].reshape(-1), sd3[idx].reshape(-1), inv, args.iterations),
+                                args.cpu_seconds, log)
+            if ref is not None:
+                result["cpu_baseline"]["reference"] = ref
     print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+        if gathered_ok is False:
+            sys.exit(3)                                            # a wrong gather must not look like a clean scaling number
 
 
 if __name__ == "__main__":

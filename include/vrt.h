@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VRT_ABI_VERSION 2
+#define VRT_ABI_VERSION 3
 
 /* element types: DiffType / DirType of the reference's template instantiations
  * (cuda_volume_raytracer.cu:992-1049) */
@@ -52,7 +52,9 @@ typedef enum vrt_status {
 /* struct Options, types.h:83-91.  Zero-initialise, then call vrt_options_default(). */
 typedef struct vrt_options {
     int32_t  loglevel;       /* _loglevel: <0 prints progress to stdout (cuda_volume_raytracer.cu:823, 948) */
-    uint64_t minimum_gpu;    /* _minimum_gpu (0x80): kept for ABI parity; this engine always runs on the GPU */
+    uint64_t minimum_gpu;    /* _minimum_gpu (0x80): the reference keeps calls with no more rays than this on the CPU
+                                (cuda_volume_raytracer.cu:805); this engine has no CPU path and always runs on the GPU, but a
+                                multi-device handle keeps such a call on its primary device instead of cutting it into bands */
     int32_t  write_instance; /* _write_instance: kept for ABI parity (debug record/replay is out of scope) */
     uint64_t max_cpu;        /* _max_cpu (256): kept for ABI parity; unused (no CPU path) */
     int32_t  device;         /* extension: HIP device ordinal, -1 = current device */
@@ -60,7 +62,7 @@ typedef struct vrt_options {
     int32_t  sort_rays;      /* extension: 0 = auto (3 for >= 4096 rays), 1 = tile ordering, 2 = tile ordering with per-ray length buckets,
                                 3 = tile ordering + wavefronts launched longest-first, -1 = keep caller order */
     int32_t  slab_lds_bytes; /* extension: LDS bytes per wavefront for the slab kernel, 0 = default (10240, or 6144 for ray sets
-                                denser than 8 rays per voxel column); rounded up to one of 4096 5120 6144 8192 10240 12288 16384 */
+                                denser than 8 rays per voxel column); rounded up to one of 6144 8192 10240 12288 16384 */
     int32_t  absorption;     /* extension, opt-in: 1 = run the absorption branch the reference compiles out
                               * (cuda_volume_raytracer.cu:337-341): per step brightness -= min(brightness,
                               * 0xFFFFFFFF - translucency[voxel]); stop when brightness < min_brightness;
@@ -69,14 +71,23 @@ typedef struct vrt_options {
                               * can execute this branch; the checker is oracle/vrt_oracle.c's restatement. */
     int32_t  schedule;       /* extension: slab-kernel scheduling. 0 = auto, 1 = static (one wavefront per group of 64
                                 rays, hardware dispatch order), 2 = persistent wavefronts drawing groups from a counter,
-                                3 = persistent and time-sliced (a group marches 1024 wave-steps, parks its ray state and is
-                                resumed by whichever wavefront draws its next ticket; all groups advance and end together) */
-    int32_t  devices;        /* extension, read at vrt_create: bit mask of HIP device ordinals the handle spans (bit d = device d),
-                              * 0 = only `device` (default), -1 = every visible device.  The field is replicated on each of
-                              * them, as the reference's constructor does (cuda_volume_raytracer.cu:676-686), and the
-                              * host-pointer calls (vrt_trace) cut the rays into one contiguous band per device, the way
-                              * the reference spreads its chunks over all devices (.cu:804-912).  Device-pointer calls use
-                              * the primary device (`device`, or the lowest bit of the mask when device = -1). */
+                                3 = persistent and time-sliced (a group marches one slice -- 1.15 x the mean group length the
+                                pre-march estimated, or 1024 wave-steps without an estimate -- parks its ray state and is resumed
+                                by whichever wavefront draws the item from the FIFO; the long groups' remainders end the launch).
+                                In auto mode the engine times its first four launches of a workload shape alternately with 2 and
+                                3 and keeps the faster (vrt_engine_last_schedule tells which a launch used); a launch that runs
+                                more than 15 % off the tuned time three times in a row starts the trials again. */
+    int32_t  devices;        /* extension, read at vrt_create / vrt_scene_create: bit mask of HIP device ordinals the handle spans
+                              * (bit d = device d), 0 = only the primary (default), -1 = every visible device.  The primary is
+                              * `device`, or the caller's current device when device = -1; the mask adds replicas.  The field
+                              * (and a scene's ior / density volume) is replicated on each of them, all copies in flight at once,
+                              * as the reference's constructor does (cuda_volume_raytracer.cu:676-686), and EVERY trace call cuts
+                              * the rays into one contiguous band per device, the way the reference spreads its chunks over all
+                              * devices (.cu:804-912): host-pointer calls upload / march / download each band on its device;
+                              * device-pointer calls leave the arrays on the primary device and the other devices read and write
+                              * their bands through peer access (xGMI), forked from and joined into the caller's stream by events.
+                              * Memory: one field copy per device of the mask -- under one process per GPU with all devices
+                              * visible, -1 makes every rank replicate everywhere; give such ranks devices = 0. */
     int32_t  host_lanes;     /* extension: chunks a host-pointer call is cut into per device (pipelined over up to 4 streams so
                               * that uploads and downloads overlap the march), 0 = auto = 1 (measured best: every chunk pays
                               * its own ray ordering and launch tail) */
@@ -158,6 +169,17 @@ int vrt_trace_device(vrt_handle h, int dir_type, size_t nrays,
                      uint32_t *d_path, const float *invscale, uint32_t min_brightness,
                      uint32_t iterations, void *stream, const vrt_options *opt);
 
+/*
+ * Completion status of the device-pointer calls issued on a handle so far (all of its devices): waits for the most recent
+ * one and returns VRT_OK, or VRT_ERR_HIP if the time-sliced schedule had to give up a wait since the last status call
+ * ("a wavefront gave up waiting": some rays were left unfinished -- the waits are bounded so that a launch can never hang,
+ * and a bound that is hit must not pass silently).  The condition is sticky until it has been reported once.  The
+ * host-pointer calls (vrt_trace, vrt_scene_trace) check it themselves and leave the output arrays untouched on failure.
+ * The reference reports device failures by throwing from trace_rays_cu (HANDLE_ERROR, cuda_volume_raytracer.cu:54-63);
+ * an asynchronous call cannot, hence this function.
+ */
+int vrt_trace_status(vrt_handle h);
+
 /* Replaces TraceRaysCu<DiffType>::~TraceRaysCu() (cuda_volume_raytracer.cu:974-989). NULL is a no-op. */
 void vrt_destroy(vrt_handle h);
 
@@ -175,6 +197,18 @@ float vrt_engine_last_march_ms(vrt_handle h);
 float vrt_engine_last_march_clock_ghz(vrt_handle h);
 /* Number of devices (engines) behind a handle: 1 + replicas made for vrt_options.devices. */
 int vrt_engine_replica_count(vrt_handle h);
+/* Schedule the most recent march kernel of the handle's primary engine was launched with: 1 static, 2 persistent wavefronts
+ * drawing whole groups, 3 persistent and time-sliced (see vrt_options.schedule); 0 = the direct kernel, or nothing launched
+ * yet.  bench.py uses it to pick the counter profile of the kernel that actually ran. */
+int vrt_engine_last_schedule(vrt_handle h);
+/* Copies the first `bytes` bytes of the resident interleaved field ({dx,dy,dz,w} per voxel, index ((x*By)+y)*Bz+z: the
+ * array the reference's constructor builds on the host, cuda_volume_raytracer.cu:654-669) to host memory.  Tests compare
+ * the scene build's output with the reference's through it. */
+int vrt_engine_download_field(vrt_handle h, void *host_dst, size_t bytes);
+/* What the engine learnt from its one scan of the field: bounds4 = max |dx|, max |dy|, max |dz| and an upper bound of the
+ * longest gradient vector (they bound the change of a direction per step for the proven rounds); *flags bit 0 = every
+ * value is zero or within [2^-55, 2^78), i.e. bricks may be stored prescaled without a per-brick test. */
+int vrt_engine_field_scan(vrt_handle h, float *bounds4, uint32_t *flags);
 /* The contiguous cut of n rays into `parts` bands that multi-device handles and the chunk pipeline use
  * (begin[0..parts], whole groups of 64 rays where possible).  Exposed for tests. */
 int vrt_debug_band_cut(size_t n, size_t parts, size_t *begin);
@@ -257,7 +291,9 @@ int vrt_scene_trace_device(vrt_scene_handle s, int dir_type, size_t nrays, const
                            uint32_t *d_remaining_light, uint32_t *d_path, const float *invscale,
                            uint32_t min_brightness, uint32_t iterations, void *stream, const vrt_options *opt);
 /* Waits for the most recent vrt_scene_trace_device call of the scene and returns VRT_OK, VRT_ERR_RAY_RANGE
- * ("ray i is not in 0 to ...", image_util.cpp:690-695) or VRT_ERR_SCENE ("Normalize length failed", :705-708). */
+ * ("ray i is not in 0 to ...", image_util.cpp:690-695), VRT_ERR_SCENE ("Normalize length failed", :705-708) or what
+ * vrt_trace_status reports for the march.  Ray errors accumulate over the device-pointer calls since the previous status
+ * call (the lowest failing ray index of any of them is reported) and are cleared by it. */
 int vrt_scene_trace_status(vrt_scene_handle s);
 
 /* Replaces RaytraceScene::~RaytraceScene (image_util.cpp:774-778). */

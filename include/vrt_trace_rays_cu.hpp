@@ -14,6 +14,7 @@
 #include <stdexcept>
 #include <string>
 #include <type_traits>
+#include <cstdlib>
 #include <vector>
 
 #include "vrt.h"
@@ -68,6 +69,7 @@ public:
         vrt_options o;
         vrt_options_default(&o);
         o.devices = -1;
+        if (const char *m = std::getenv("VRT_DEVICES")) o.devices = (int32_t)std::strtol(m, nullptr, 0);   // one process per GPU: VRT_DEVICES=0
         check(vrt_create(&_h, (int)output_sizes_.size(), _output_sizes.data(), elem_type<DiffType>::value, d.data(),
                          translucency_cropped_.data(), translucency_cropped_.size(), &o));
     }

@@ -12,6 +12,7 @@
 // the reference is copied here.  The engine handle is kept in the class's spare `void *_tex` member
 // (cuda_volume_raytracer.h:70), which the CPU build never touches.
 #include <cstdint>
+#include <cstdlib>
 #include <memory>
 #include <stdexcept>
 #include <vector>
@@ -37,9 +38,13 @@ TraceRaysCu<DiffType>::TraceRaysCu(std::vector<size_t> const &bounds, std::vecto
     // the reference replicates the field on every CUDA device (cuda_volume_raytracer.cu:676-686) and trace_rays_cu spreads
     // its chunks over all of them (:804-912): the handle spans every visible device and vrt_trace cuts the rays into
     // one band per device (calls with no more than Options::_minimum_gpu rays stay on one, as :805 keeps them on the CPU)
+    // The primary engine lives on the caller's current device; the mask adds replicas.  A host application that runs one
+    // process per GPU with every device visible would replicate everywhere from every process: VRT_DEVICES (a bit mask,
+    // 0 = the current device only) narrows it without touching the reference's code.
     vrt_options o;
     vrt_options_default(&o);
     o.devices = -1;
+    if (const char *m = std::getenv("VRT_DEVICES")) o.devices = static_cast<int32_t>(std::strtol(m, nullptr, 0));
     vrt_handle h = nullptr;
     check(vrt_create(&h, static_cast<int>(bounds.size()), _output_sizes.data(), elem<DiffType>::value, d.data(),
                      translucency_cropped.data(), translucency_cropped.size(), &o));

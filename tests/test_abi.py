@@ -30,7 +30,7 @@ def test_header_symbols_exported():
 
 def test_abi_version_and_options_layout():
     lib = capi.load()
-    assert lib.vrt_abi_version() == 2
+    assert lib.vrt_abi_version() == 3
     o = capi.default_options()
     # struct Options defaults, /root/reference/src/types.h:90
     assert (o.loglevel, o.minimum_gpu, o.write_instance, o.max_cpu) == (0, 0x80, 0, 256)

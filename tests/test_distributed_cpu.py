@@ -171,3 +171,15 @@ def test_strong_scaling_bands_tile_the_fixed_lattice():
         assert bench.lattice_rows(cfg, world, "weak") == cfg["R"] * world
         w = [bench.make_rays(cfg, r, world, scaling="weak") for r in range(world)]
         assert all(p[0].size // 3 == cfg["R"] ** 2 for p in w)
+
+
+def test_sample_gathered_covers_every_rank():
+    """bench.py's N > 1 self-check samples the gathered records evenly over the whole job; every rank's band must be hit
+    (a band swapped or shifted by the gather then cannot pass), indices stay inside the rank's count."""
+    for counts in ([1000, 1000], [5, 100000, 7, 3], [0, 64, 64], [1 << 20] * 8):
+        pick = D.sample_gathered(counts, 4096)
+        assert [r for r, _ in pick] == list(range(len(counts)))
+        for (r, idx), c in zip(pick, counts):
+            assert (idx.size > 0) == (c > 0)
+            assert idx.size == 0 or (idx.min() >= 0 and idx.max() < c and np.all(np.diff(idx) > 0))
+        assert sum(idx.size for _, idx in pick) >= min(4096, sum(counts)) - 1

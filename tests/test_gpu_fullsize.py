@@ -130,6 +130,107 @@ def test_config4_tiled():
     eng.close()
 
 
+def test_config5_full_size():
+    """BASELINE config 5 as written and at its real size: 1024^3 uint8 density + 256-entry transfer function -> scene
+    build on the device (8.5 GB int16 field) -> 1024 x 1024 orthographic rays, opaque cores (the early-out stress case).
+      * the default launch (auto schedule: the engine's tuner runs the whole-group and the time-sliced schedule in turn
+        and settles) gives the same bits on every call, equal to the direct kernel in caller order, to the slab kernel in
+        caller order and to the explicit schedules;
+      * roughly half of the rays stop on the opacity test (w > 0) inside the field, before the cap; the others leave it;
+      * two blocks of 40 x 40 rays (through an opaque core / near the rim) are checked bit for bit against the oracle.  The
+        oracle's own scene build of the whole 1024^3 volume would take minutes on the host, so it builds only the
+        sub-volume those rays visit: their paths are traced on the GPU (path output), the bounding box of every
+        position of every sampled ray plus the stencil's and the interpolation's reach is cut out of the density, and
+        the oracle builds and marches that (stencil, field and march are translation invariant in whole voxels)."""
+    torch = pytest.importorskip("torch")
+    import bench
+    cfg = bench.CONFIGS[5]
+    N, R = cfg["N"], cfg["R"]
+    dev = torch.device("cuda", 0)
+    eng, scene, bounds, _, _, (dens, lut_ior, lut_tr) = bench.build_engine(cfg, dev)
+    assert eng.field_bytes == 8 * (N - 2) ** 3
+    sp, sd = bench.make_rays(cfg, 0, 1)
+    n = sp.size // 3
+    assert n == R * R
+    d_sp = torch.from_numpy(sp.view(np.int32)).to(dev)
+    d_sd = torch.from_numpy(sd).to(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run(**kw):
+        rec = D.alloc_record(n, dev)
+        ep, ed, ei, rl = D.record_views(rec, n)
+        eng.trace_device(capi.VRT_F32, n, d_sp.data_ptr(), d_sd.data_ptr(), ep.data_ptr(), ed.data_ptr(), ei.data_ptr(),
+                         rl.data_ptr(), [1, 1, 1], 100000, stream=stream, options=capi.default_options(**kw))
+        eng.status()
+        return rec.cpu().numpy(), eng.last_schedule()
+
+    a, _ = run()
+    seen = set()
+    for call in range(6):                                          # trials 2, 3, 2, 3, then the settled choice
+        b, sched = run()
+        seen.add(sched)
+        assert np.array_equal(a, b), "auto schedule, call %d (schedule %d)" % (call, sched)
+    assert seen >= {2, 3}, seen                                    # both persistent schedules really ran
+    assert np.array_equal(a, run(kernel=capi.KERNEL_DIRECT, sort_rays=-1)[0]), "slab (tile order) vs direct (caller order)"
+    assert np.array_equal(a, run(kernel=capi.KERNEL_SLAB, sort_rays=-1, schedule=1)[0]), "slab in caller order, static schedule"
+    assert np.array_equal(a, run(kernel=capi.KERNEL_SLAB, schedule=3)[0]), "time-sliced schedule"
+
+    ep, ed, ei, rl = a[:3 * n].view(np.uint32), a[3 * n:6 * n].view(np.uint32), a[6 * n:7 * n].view(np.uint32), a[7 * n:].view(np.uint32)
+    assert np.all(rl == 0xFFFFFFFF)
+    B = np.array(bounds, np.int64)
+    cell = ep.reshape(-1, 3).astype(np.int64) >> 16
+    inside = np.all(cell < B - 1, axis=1)                          # stopped inside the field: only the w > 0 test does that
+    assert ei.max() < 100000, "no ray ran into the cap"
+    frac = float(inside.mean())
+    assert 0.25 < frac < 0.75, "share of rays stopped by the opacity test: %.3f" % frac
+
+    # ---- oracle on two blocks of rays, through the sub-volume they visit
+    iters_p = 8192
+    assert int(ei.max()) < iters_p
+    dens3 = dens.reshape(N, N, N)
+    rows = np.arange(R)
+    hit_rows = inside.reshape(R, R)
+    r_hit, c_hit = np.argwhere(hit_rows)[len(np.argwhere(hit_rows)) // 2]       # a ray that hits a core: block around it
+    blocks = [(int(np.clip(r_hit - 20, 0, R - 40)), int(np.clip(c_hit - 20, 0, R - 40))), (60, 930)]
+    checked = 0
+    for (r0, c0) in blocks:
+        idx = (rows[r0:r0 + 40, None] * R + rows[None, c0:c0 + 40]).reshape(-1)
+        m = idx.size
+        bsp, bsd = sp.reshape(-1, 3)[idx].reshape(-1).copy(), sd.reshape(-1, 3)[idx].reshape(-1).copy()
+        t_sp = torch.from_numpy(bsp.view(np.int32)).to(dev)
+        t_sd = torch.from_numpy(bsd).to(dev)
+        rec = D.alloc_record(m, dev)
+        pep, ped, pei, prl = D.record_views(rec, m)
+        path = torch.zeros(m * iters_p * 3, dtype=torch.int32, device=dev)
+        eng.trace_device(capi.VRT_F32, m, t_sp.data_ptr(), t_sd.data_ptr(), pep.data_ptr(), ped.data_ptr(), pei.data_ptr(),
+                         prl.data_ptr(), [1, 1, 1], iters_p, d_path=path.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(pei.cpu().numpy().view(np.uint32), ei[idx]), "the path run marches the same steps"
+        P = path.cpu().numpy().view(np.uint32).astype(np.int64).reshape(m * iters_p, 3)
+        del path
+        P[P >= 2 ** 31] -= 2 ** 32                                 # positions that wrapped below zero
+        c = P >> 16
+        cmin, cmax = c.min(axis=0), c.max(axis=0)
+        del P, c
+        lo = np.maximum(cmin - 1, 0)
+        hi_field = np.minimum(cmax + 2, B - 1)                     # last field voxel the sub-field must hold
+        sub = np.ascontiguousarray(dens3[lo[0]:hi_field[0] + 3, lo[1]:hi_field[1] + 3, lo[2]:hi_field[2] + 3])
+        sdims = [int(x) for x in sub.shape]
+        assert sub.size < 200e6, sdims                             # the whole point: far smaller than 1024^3
+        hx, hy, hz, tc, ob = oracle.port.scene_build(sdims, lut_ior[sub.reshape(-1)], lut_tr[sub.reshape(-1)])
+        field = oracle.port.interleave(hx, hy, hz, tc)
+        del hx, hy, hz
+        shift = (lo.astype(np.uint32) << 16)
+        ssp = (bsp.reshape(-1, 3) - shift[None, :]).reshape(-1)
+        want = oracle.port.trace(field, ob, ssp, bsd, [1, 1, 1], 100000)
+        assert np.array_equal((want["end_position"].reshape(-1, 3) + shift[None, :]).astype(np.uint32), ep.reshape(-1, 3)[idx]), (r0, c0)
+        assert np.array_equal(want["end_direction"].view(np.uint32).reshape(-1, 3), ed.reshape(-1, 3)[idx]), (r0, c0)
+        assert np.array_equal(want["end_iteration"], ei[idx]), (r0, c0)
+        checked += m
+    assert checked >= 3000
+    scene.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("fdt", [np.float32, np.int16])
 def test_wide_field_stages_through_64_bit_addresses(fdt):

@@ -133,3 +133,48 @@ def test_replay_reference_dump_files(golden_dir, capsys):
     assert replay.main([os.path.join(golden_dir, "debug_scene_instance"), os.path.join(golden_dir, "debug_ray_instance")]) == 0
     text = capsys.readouterr().out
     assert "begin " in text and ("end " + " ".join(str(int(x)) for x in g["end_position"][:192])) in text
+
+
+@pytest.mark.parametrize("kind", ["f32", "f32_lut", "u32", "u32_lut"])
+@pytest.mark.parametrize("dims", [(3, 3, 3), (9, 11, 35), (37, 10, 70), (41, 36, 33)])
+def test_scene_build_field_bits(monkeypatch, kind, dims):
+    """Row f-1: the field the scene build leaves in HBM, voxel for voxel, against the oracle's scene build (which is
+    pinned to the reference's, tests/test_oracle_vs_reference.py) -- for the LDS-tiled kernel (default) and the
+    per-voxel kernel of round 2, at extents that are not multiples of the tile (8 x 32 outputs, 32 planes per workgroup),
+    for array and LUT sources of both families.  The field scan fused into the tiled kernel must give the numbers of the
+    separate scan."""
+    rng = np.random.RandomState(hash((kind,) + dims) % (2 ** 31))
+    nvox = dims[0] * dims[1] * dims[2]
+    is_f = kind.startswith("f32")
+    dens = rng.randint(0, 256, nvox).astype(np.uint8)
+    if is_f:
+        lut_ior = (1.0 + rng.rand(256) * 0.8).astype(np.float32)
+    else:
+        lut_ior = np.round((1.0 + rng.rand(256) * 0.8) * 65536).astype(np.uint32)
+    lut_tr = np.where(rng.rand(256) < 0.8, 0xFFFFFFFF, rng.randint(0, 2 ** 31, 256)).astype(np.uint32)
+    if kind.endswith("lut"):
+        # smooth-ish density so that the integer family's int16 derivative does not overflow
+        dens = (np.clip(np.cumsum(rng.randint(-1, 2, nvox)), 0, 255)).astype(np.uint8)
+        ior, tr = lut_ior[dens], lut_tr[dens]
+    else:
+        base = 1.0 + 0.3 * rng.rand(nvox)
+        ior = base.astype(np.float32) if is_f else np.round(base * 65536).astype(np.uint32)
+        tr = np.where(rng.rand(nvox) < 0.9, 0xFFFFFFFF, rng.randint(0, 2 ** 31, nvox)).astype(np.uint32)
+    try:
+        hx, hy, hz, tc, _ = oracle.port.scene_build(list(dims), ior, tr)
+    except Exception as ex:                                  # the oracle raises what the reference throws (overflow): same on the GPU
+        with pytest.raises(capi.VrtError):
+            capi.Scene(list(dims), ior, tr)
+        return
+    want = oracle.port.interleave(hx, hy, hz, tc)
+    fields, scans = {}, {}
+    for mode in ("tiled", "pervoxel"):
+        monkeypatch.setenv("VRT_SCENE_BUILD", mode)
+        sc = capi.Scene.from_lut(list(dims), dens, lut_ior, lut_tr) if kind.endswith("lut") else capi.Scene(list(dims), ior, tr)
+        with sc:
+            eng = sc.engine()
+            fields[mode] = eng.download_field()
+            scans[mode] = eng.field_scan()
+    for mode in fields:
+        assert np.array_equal(fields[mode].reshape(-1).view(np.uint8), np.asarray(want).reshape(-1).view(np.uint8)), mode
+    assert np.array_equal(scans["tiled"][0].view(np.uint32), scans["pervoxel"][0].view(np.uint32)) and scans["tiled"][1] == scans["pervoxel"][1]

@@ -21,7 +21,8 @@ ABI_SYMBOLS = (
     "vrt_engine_field_device_ptr", "vrt_engine_last_march_ms", "vrt_engine_debug_stats", "vrt_selftest_ilen2", "vrt_selftest_round", "vrt_selftest_stage_division",
     "vrt_last_error", "vrt_scene_create", "vrt_scene_create_lut", "vrt_scene_trace", "vrt_scene_destroy", "vrt_scene_engine",
     "vrt_engine_last_march_clock_ghz", "vrt_engine_replica_count", "vrt_debug_band_cut", "vrt_scene_trace_device",
-    "vrt_scene_trace_status",
+    "vrt_scene_trace_status", "vrt_trace_status", "vrt_engine_last_schedule",
+    "vrt_engine_download_field", "vrt_engine_field_scan",
 )
 
 
@@ -99,6 +100,11 @@ def load():
         L.vrt_scene_trace_device.argtypes = [vp, C.c_int, sz, u32p, vp, u32p, vp, u32p, u32p, u32p, vp, C.c_uint32,
                                              C.c_uint32, vp, C.POINTER(Options)]
         L.vrt_scene_trace_status.argtypes = [vp]
+    if hasattr(L, "vrt_trace_status"):               # ABI 3
+        L.vrt_trace_status.argtypes = [vp]
+        L.vrt_engine_last_schedule.argtypes = [vp]
+        L.vrt_engine_download_field.argtypes = [vp, vp, sz]
+        L.vrt_engine_field_scan.argtypes = [vp, vp, vp]
     if hasattr(L, "vrt_scene_create"):
         L.vrt_scene_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_size_t), C.c_int, vp, u32p, sz,
                                        C.POINTER(Options)]
@@ -248,6 +254,29 @@ class Engine:
         """Shader clock the most recent march kernel ran at (s_memtime / s_memrealtime of one of its wavefronts)."""
         return float(load().vrt_engine_last_march_clock_ghz(self._h))
 
+    def download_field(self):
+        """The resident interleaved field as a host array [nvox, 4] (float32 or int16)."""
+        dt = np.float32 if self.field_type == VRT_F32 else np.int16
+        out = np.empty((self.field_bytes // (4 * np.dtype(dt).itemsize), 4), dt)
+        check(load().vrt_engine_download_field(self._h, _np_ptr(out), out.nbytes))
+        return out
+
+    def field_scan(self):
+        """(max|dx|, max|dy|, max|dz|, bound of the longest gradient vector), flags -- from the engine's field scan."""
+        b = np.zeros(4, np.float32)
+        f = np.zeros(1, np.uint32)
+        check(load().vrt_engine_field_scan(self._h, _np_ptr(b), _np_ptr(f)))
+        return b, int(f[0])
+
+    def last_schedule(self):
+        """Schedule of the most recent march launch: 1 static, 2 persistent, 3 time-sliced, 0 direct kernel / none."""
+        return int(load().vrt_engine_last_schedule(self._h))
+
+    def status(self):
+        """vrt_trace_status: wait for the device-pointer calls issued so far and raise if the time-sliced schedule gave
+        up a wait (results incomplete)."""
+        check(load().vrt_trace_status(self._h))
+
     @property
     def replica_count(self):
         """Devices (engines) behind the handle: 1 + replicas made for options.devices."""
@@ -275,8 +304,9 @@ class Engine:
         return dict(end_position=ep, end_direction=ed, end_iteration=ei, remaining_light=rl, path=path)
 
     def trace_device(self, dir_type, nrays, d_start_pos, d_start_dir, d_end_pos, d_end_dir, d_end_iter,
-                     d_remaining_light, invscale, iterations, d_path=0, stream=0, min_brightness=0, options=None):
-        """vrt_trace_device on raw device pointers (ints); asynchronous on `stream`."""
+                     d_remaining_light, invscale, iterations, d_path=0, stream=0, min_brightness=0, options=None, check_status=False):
+        """vrt_trace_device on raw device pointers (ints); asynchronous on `stream` unless check_status is set, which
+        waits for the call and raises on a scheduler failure (vrt_trace_status)."""
         L = load()
         inv = np.ascontiguousarray(invscale, dtype=np.float32)
         check(L.vrt_trace_device(self._h, dir_type, int(nrays), C.c_void_p(int(d_start_pos)),
@@ -285,6 +315,8 @@ class Engine:
                                  C.c_void_p(int(d_path)) if d_path else None, _np_ptr(inv), int(min_brightness),
                                  int(iterations), C.c_void_p(int(stream)) if stream else None,
                                  C.byref(options) if options is not None else None))
+        if check_status:
+            self.status()
 
     def close(self):
         if self._h is not None and _lib is not None and self._owned:

@@ -123,8 +123,15 @@ struct Workspace {
     hipStream_t stream = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;   // around the most recent march kernel of this lane
     hipEvent_t ev_done = nullptr;                      // after the last launch that used these buffers
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // multi-device device-pointer calls: fan-out from / join into the caller's stream
     bool ev_valid = false, used = false;
     bool last_sliced = false;                          // the lane's most recent march used the time-sliced schedule
+    int last_schedule = 0;                             // schedule of the lane's most recent march: 1 static, 2 persistent, 3 time-sliced; 0 = direct kernel / none
+    // The time-sliced schedule bounds every wait and raises an error word instead of hanging (vrt_slab.h).  The word lives in
+    // pinned host memory the kernel can write (a store happens only on that path: no cost otherwise) and stays raised until
+    // somebody asks (vrt_trace_status / the host-pointer calls), so device-pointer callers can find out too.
+    uint32_t *pin_sched_err = nullptr;                 // host address
+    uint32_t *dev_sched_err = nullptr;                 // the same word as the device sees it
     // Schedule auto-tuning (vrt_options.schedule = 0): whether time slicing pays depends on how unevenly the groups of a
     // launch run, which is not known beforehand (config 5: 14.7 -> 13.7 ms; a 1448 x 1448 lattice on 512^3: 13.8 -> 15.5).
     // The first four launches of a workload shape alternate between the whole-group and the time-sliced schedule, HIP
@@ -134,6 +141,7 @@ struct Workspace {
         unsigned long long key = 0;
         int state = 0;                                 // 0..3: trial launches (2, 3, 2, 3); 4: waiting for the events; 5: decided
         int choice = 2;
+        int drift = 0;                                 // consecutive launches whose duration was > 15 % off the tuned one (state 5)
         hipEvent_t ev[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // [trial][begin | end]
         float ms[2] = {0.0f, 0.0f};
     } tuner;
@@ -145,10 +153,13 @@ struct Workspace {
     size_t stats_count = 0;
     DevBuf in_pos, in_dir, out_pos, out_dir, out_iter, out_light, path;   // device staging of host-pointer calls
     DevBuf pro_pos, pro_dir, err;  // scene layer: prologue outputs of device-pointer calls, error words
+    DevBuf err_sticky;             // scene layer, device-pointer calls: error words accumulated over calls until vrt_scene_trace_status reads them
     void *pin_err = nullptr;       // pinned host copy of the error words (scene layer)
-    DevBuf *all[20] = {&sort_keys, &sort_keys_alt, &sort_vals, &sort_vals_alt, &sort_tmp, &sort_bounds, &group_ctr, &clock,
-                       &stats, &in_pos, &in_dir, &out_pos, &out_dir, &out_iter, &out_light, &path, &pro_pos, &pro_dir,
-                       &park, &slice_flags};
+    std::vector<DevBuf *> all()
+    {
+        return {&sort_keys, &sort_keys_alt, &sort_vals, &sort_vals_alt, &sort_tmp, &sort_bounds, &group_ctr, &clock, &stats, &in_pos,
+                &in_dir, &out_pos, &out_dir, &out_iter, &out_light, &path, &pro_pos, &pro_dir, &park, &slice_flags, &err, &err_sticky};
+    }
 };
 constexpr int kLanes = 4;
 
@@ -171,6 +182,7 @@ struct vrt_engine {
     // multi-device handles (vrt_options.devices): the field replicated on other devices, as the reference's ctor does
     // (cuda_volume_raytracer.cu:676-686); host-pointer calls cut the rays into one contiguous band per device.
     std::vector<vrt_engine *> replicas;
+    bool peer_ok = true;           // replica only: its device can read and write the primary device's memory (device-pointer calls)
     vrt_options opt;
 };
 
@@ -249,6 +261,19 @@ __global__ __launch_bounds__(256) void k_field_absmax(const VoxT *f, size_t n, u
     }
 }
 
+// the five words of the field scan (k_field_absmax, or fused into the tiled scene build) -> the engine's bounds and flags
+void engine_apply_absmax(vrt_engine *e, const uint32_t h[5])
+{
+    memcpy(e->gmax, h, 3 * sizeof(uint32_t));
+    float q;
+    memcpy(&q, &h[3], 4);
+    e->gnorm = (float)(std::sqrt((double)q) * (1.0 + 1.0 / 1024.0));     // >= the longest gradient vector (float sum of squares: 3 roundings)
+    // prescale_ok (vrt_slab.h) for the whole field at once: every non-zero |value| in [2^-55, 2^78), which also rules out
+    // NaN and infinity (their patterns are the largest); h[4] = ~(smallest non-zero pattern - 1), 0 for an all-zero field
+    const uint32_t hi = std::max(h[0], std::max(h[1], h[2])), lo = h[4] ? ~h[4] + 1u : 0x7F800000u;
+    e->field_flags = (e->field_type == VRT_I16 || (hi < ((127u + 78u) << 23) && lo >= ((127u - 55u) << 23))) ? vrt::kFieldPrescaleOk : 0u;
+}
+
 int engine_field_absmax(vrt_engine *e, hipStream_t s)
 {
     uint32_t *d_out = nullptr, h[5] = {0, 0, 0, 0, 0};
@@ -264,14 +289,7 @@ int engine_field_absmax(vrt_engine *e, hipStream_t s)
     if (err == hipSuccess) err = hipStreamSynchronize(s);
     (void)hipFree(d_out);
     HIP_TRY(err);
-    memcpy(e->gmax, h, 3 * sizeof(uint32_t));
-    float q;
-    memcpy(&q, &h[3], 4);
-    e->gnorm = (float)(std::sqrt((double)q) * (1.0 + 1.0 / 1024.0));     // >= the longest gradient vector (float sum of squares: 3 roundings)
-    // prescale_ok (vrt_slab.h) for the whole field at once: every non-zero |value| in [2^-55, 2^78), which also rules out
-    // NaN and infinity (their patterns are the largest); h[4] = ~(smallest non-zero pattern - 1), 0 for an all-zero field
-    const uint32_t hi = std::max(h[0], std::max(h[1], h[2])), lo = h[4] ? ~h[4] + 1u : 0x7F800000u;
-    e->field_flags = (e->field_type == VRT_I16 || (hi < ((127u + 78u) << 23) && lo >= ((127u - 55u) << 23))) ? vrt::kFieldPrescaleOk : 0u;
+    engine_apply_absmax(e, h);
     return VRT_OK;
 }
 
@@ -304,9 +322,8 @@ int engine_alloc(vrt_engine **pe, const uint16_t *bounds, int field_type, size_t
     if (opt) e->opt = *opt; else vrt_options_default(&e->opt);
     int dev = e->opt.device;
     if (e->opt.devices == -1) e->opt.devices = (int32_t)(ndev >= 32 ? 0xFFFFFFFFu : ((1u << ndev) - 1u));
-    if (dev < 0 && e->opt.devices != 0) {                // no primary named: the lowest device of the mask
-        for (int d = 0; d < 32; ++d) if ((uint32_t)e->opt.devices >> d & 1u) { dev = d; break; }
-    }
+    // no primary named: the caller's current device (the mask only adds replicas), so that under one process per GPU
+    // with every device visible each rank's handle still lives on its own device
     if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
     if (dev >= ndev) { delete e; return fail(VRT_ERR_INVALID_ARGUMENT, "device %d out of range (%d devices)", dev, ndev); }
     e->device = dev;
@@ -324,17 +341,22 @@ int workspace_init(Workspace &w)
     HIP_TRY(hipEventCreate(&w.ev_begin));
     HIP_TRY(hipEventCreate(&w.ev_end));
     HIP_TRY(hipEventCreateWithFlags(&w.ev_done, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&w.ev_join, hipEventDisableTiming));
+    HIP_TRY(hipHostMalloc((void **)&w.pin_sched_err, sizeof(uint32_t), hipHostMallocMapped));
+    *w.pin_sched_err = 0u;
+    HIP_TRY(hipHostGetDevicePointer((void **)&w.dev_sched_err, w.pin_sched_err, 0));
     return VRT_OK;
 }
 
 void workspace_free(Workspace &w)
 {
     if (w.stream) { (void)hipStreamSynchronize(w.stream); (void)hipStreamDestroy(w.stream); }
-    for (hipEvent_t ev : {w.ev_begin, w.ev_end, w.ev_done}) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : {w.ev_begin, w.ev_end, w.ev_done, w.ev_fork, w.ev_join}) if (ev) (void)hipEventDestroy(ev);
     for (auto &pair : w.tuner.ev) for (hipEvent_t ev : pair) if (ev) (void)hipEventDestroy(ev);
-    for (DevBuf *b : w.all) b->release();
-    w.err.release();
+    for (DevBuf *b : w.all()) b->release();
     if (w.pin_err) (void)hipHostFree(w.pin_err);
+    if (w.pin_sched_err) (void)hipHostFree(w.pin_sched_err);
     w = Workspace();
 }
 
@@ -504,6 +526,7 @@ int trace_device_impl(vrt_engine *e, Workspace &w, int dir_type, size_t nrays, c
     // persistent (as many wavefronts as the GPU holds, each drawing groups from a counter)
     p.group_counter = nullptr;
     int tuner_trial = -1;
+    int launched_schedule = 0;
     {
         const size_t groups = (nrays + 63) / 64;
         int schedule = o.schedule;
@@ -537,23 +560,40 @@ int trace_device_impl(vrt_engine *e, Workspace &w, int dir_type, size_t nrays, c
                         t.ms[1] = std::min(ms[1], ms[3]);
                         t.choice = t.ms[1] < 0.99f * t.ms[0] ? 3 : 2;
                         t.state = 5;
+                        t.drift = 0;
                         schedule = t.choice;
                         if (o.loglevel < 0) printf("schedule tuned: whole groups %.3f ms, time-sliced %.3f ms -> %d\n", t.ms[0], t.ms[1], t.choice);
                     }
                     (void)hipGetLastError();                 // hipErrorNotReady from the queries is not an error
                 } else {
                     schedule = t.choice;
+                    // The key cannot see the rays themselves: another ray set of the same size and type would keep a schedule
+                    // that was timed on a different work distribution.  The previous launch's duration is free to read once
+                    // it has finished; three launches in a row more than 15 % off the tuned time start the trials again.
+                    float prev = 0.0f;
+                    if (w.ev_valid && hipEventQuery(w.ev_end) == hipSuccess && hipEventElapsedTime(&prev, w.ev_begin, w.ev_end) == hipSuccess) {
+                        const float ref = t.ms[t.choice - 2];
+                        t.drift = (ref > 0.0f && (prev > 1.15f * ref || prev < 0.85f * ref)) ? t.drift + 1 : 0;
+                        if (t.drift >= 3) { t.state = 0; t.drift = 0; }
+                    }
+                    (void)hipGetLastError();
                 }
             }
         }
         p.park = nullptr; p.slice_flags = nullptr; p.slice_steps = 0; p.ticket_limit = 0;
         p.work_sum = nullptr; p.work_unit = (uint32_t)vrt::kCoarse; p.slice_percent = 115;
+        p.sched_err = w.dev_sched_err;
+        p.spin_limit = 1u << 22;
+        if (const char *ev = getenv("VRT_DEBUG_SPIN_LIMIT")) p.spin_limit = (uint32_t)std::max(1L, strtol(ev, nullptr, 10));   // tests: force the give-up branch
+        launched_schedule = kernel == VRT_KERNEL_SLAB ? 1 : 0;
         if (schedule >= 2 && kernel == VRT_KERNEL_SLAB && groups > 1 && geo.complete) {
-            HIP_TRY(w.group_ctr.reserve(4 * sizeof(uint32_t)));
-            HIP_TRY(hipMemsetAsync(w.group_ctr.p, 0, 4 * sizeof(uint32_t), s));
+            HIP_TRY(w.group_ctr.reserve(vrt::kCtrWords * sizeof(uint32_t)));
+            HIP_TRY(hipMemsetAsync(w.group_ctr.p, 0, vrt::kCtrWords * sizeof(uint32_t), s));
             p.group_counter = (uint32_t *)w.group_ctr.p;
             tuner_trial = trial;
+            launched_schedule = 2;
             if (schedule == 3 && !p.transl) {
+                launched_schedule = 3;
                 // time-sliced: parked state and per-group slice flags (vrt_slab.h, SCHED == 2)
                 // slice length: derived in the kernel from the pre-march's work estimates when the launch has them (the wavefront
                 // launch order was built), else 1024 wave-steps; VRT_SLICE_STEPS / VRT_SLICE_PERCENT override (development)
@@ -596,6 +636,7 @@ int trace_device_impl(vrt_engine *e, Workspace &w, int dir_type, size_t nrays, c
     w.ev_valid = true;
     w.used = true;
     w.last_sliced = p.park != nullptr;
+    w.last_schedule = launched_schedule;
     return VRT_OK;
 }
 
@@ -655,12 +696,24 @@ int trace_host_chunk(vrt_engine *e, Workspace &w, const HostCall &c, size_t off,
         HIP_TRY(hipMemcpyAsync(w.in_pos.p, c.sp + 3 * off, n * 12, hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(w.in_dir.p, (const char *)c.sd + 3 * off * dsz, n * 3 * dsz, hipMemcpyHostToDevice, s));
     }
+    // the lane's error words and prologue buffers are shared with a device-pointer call that may still be in flight on
+    // another stream: order behind it before the prologue touches them
+    if (w.used) HIP_TRY(hipStreamWaitEvent(s, w.ev_done, 0));
     int rc = hooks.pre(e, w, (uint32_t *)w.in_pos.p, w.in_dir.p, n, off, s);
     if (rc) return rc;
     rc = trace_device_impl(e, w, c.dir_type, n, (const uint32_t *)w.in_pos.p, w.in_dir.p, (uint32_t *)w.out_pos.p,
                            w.out_dir.p, (uint32_t *)w.out_iter.p, (uint32_t *)w.out_light.p,
                            c.path ? (uint32_t *)w.path.p : nullptr, c.invscale, c.iterations, s, c.opt, c.out_pos_bias,
                            c.min_brightness);
+    if (rc) return rc;
+    // ray errors (scene layer) and scheduler errors are looked at before anything is copied back, so that a failing call
+    // leaves the caller's output arrays untouched, as the reference's exceptions do (image_util.cpp:690-708 throw before the march)
+    HIP_TRY(hipStreamSynchronize(s));
+    if (const uint32_t gave_up = *(volatile uint32_t *)w.pin_sched_err) {
+        *w.pin_sched_err = 0u;
+        return fail(VRT_ERR_HIP, "time-sliced schedule: a wavefront gave up waiting (%u); results are incomplete", gave_up);
+    }
+    rc = hooks.post(e, w, n, off);
     if (rc) return rc;
     {
         Range range("vrt: download results");
@@ -673,14 +726,7 @@ int trace_host_chunk(vrt_engine *e, Workspace &w, const HostCall &c, size_t off,
                                    hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
     }
-    if (w.last_sliced) {
-        // the time-sliced schedule bounds every wait and raises its error word instead of hanging (vrt_slab.h); a
-        // raised word means rays were left unfinished -- it has never been observed, and must not pass silently
-        uint32_t words[4] = {0, 0, 0, 0};
-        HIP_TRY(hipMemcpy(words, w.group_ctr.p, sizeof words, hipMemcpyDeviceToHost));
-        if (words[2] != 0) return fail(VRT_ERR_HIP, "time-sliced schedule: a wavefront gave up waiting (%u); results are incomplete", words[2]);
-    }
-    return hooks.post(e, w, n, off);
+    return VRT_OK;
 }
 
 // Contiguous cut of `n` rays into `parts` ranges whose sizes are multiples of 64 where possible (whole wavefronts),
@@ -695,6 +741,59 @@ void band_cut(size_t n, size_t parts, std::vector<size_t> &begin)
         g0 += groups / parts + (k < groups % parts ? 1 : 0);
     }
     begin[parts] = n;
+}
+
+// Engines (devices) of a handle that one call of `nrays` rays is spread over.  Calls with no more than Options::_minimum_gpu
+// rays stay on one device (the reference keeps them on the CPU, cuda_volume_raytracer.cu:805); device-pointer calls can
+// only use replicas whose device reaches the primary's memory (peer access).
+std::vector<vrt_engine *> call_engines(vrt_engine *e0, size_t nrays, const vrt_options &o, bool need_peer)
+{
+    std::vector<vrt_engine *> engs{e0};
+    for (vrt_engine *r : e0->replicas) if (!need_peer || r->peer_ok) engs.push_back(r);
+    if (nrays < 64 * engs.size() || nrays <= o.minimum_gpu) engs.resize(1);   // too few rays to be worth spreading
+    return engs;
+}
+
+// Device-pointer call on a handle that spans several devices (the reference spreads every trace_rays_cu call over all
+// devices, cuda_volume_raytracer.cu:804-912): one contiguous band of the rays per device, each band ordered and marched by
+// its device's engine on that engine's own stream.  The arrays stay where the caller put them, on the primary device: the
+// other devices read their band's start rays and write its results straight through peer access (xGMI), at the rays' own
+// indices, so there is neither a host round trip nor a merge pass.  The caller's stream forks into the replica streams
+// through an event and joins them again: when the call returns, everything is enqueued and `s` completes after all bands.
+int trace_device_multi(const std::vector<vrt_engine *> &engs, int dir_type, size_t nrays, const uint32_t *d_sp, const void *d_sd,
+                       uint32_t *d_ep, void *d_ed, uint32_t *d_ei, uint32_t *d_rl, uint32_t *d_path, const float *invscale,
+                       uint32_t iterations, hipStream_t s, const vrt_options *opt, uint32_t out_pos_bias, uint32_t min_brightness)
+{
+    vrt_engine *e0 = engs[0];
+    if (engs.size() == 1)
+        return trace_device_impl(e0, e0->ws[0], dir_type, nrays, d_sp, d_sd, d_ep, d_ed, d_ei, d_rl, d_path, invscale, iterations, s,
+                                 opt, out_pos_bias, min_brightness);
+    std::vector<size_t> band;
+    band_cut(nrays, engs.size(), band);
+    const size_t dsz = dir_type == VRT_F32 ? 4 : 2;
+    HIP_TRY(hipEventRecord(e0->ws[0].ev_fork, s));
+    auto run_band = [&](vrt_engine *e, size_t k, hipStream_t sk) {
+        const size_t off = band[k], n = band[k + 1] - band[k];
+        if (n == 0) return (int)VRT_OK;
+        return trace_device_impl(e, e->ws[0], dir_type, n, d_sp + 3 * off, (const char *)d_sd + 3 * off * dsz, d_ep + 3 * off,
+                                 (char *)d_ed + 3 * off * dsz, d_ei + off, d_rl + off,
+                                 d_path ? d_path + off * (size_t)iterations * 3 : nullptr, invscale, iterations, sk, opt, out_pos_bias,
+                                 min_brightness);
+    };
+    for (size_t k = 1; k < engs.size(); ++k) {              // the replicas first: their host-side enqueue overlaps nothing otherwise
+        vrt_engine *r = engs[k];
+        DeviceGuard g(r->device);
+        hipStream_t sk = r->ws[0].stream;
+        HIP_TRY(hipStreamWaitEvent(sk, e0->ws[0].ev_fork, 0));
+        const int rc = run_band(r, k, sk);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(r->ws[0].ev_join, sk));
+    }
+    const int rc = run_band(e0, 0, s);
+    if (rc) return rc;
+    for (size_t k = 1; k < engs.size(); ++k) HIP_TRY(hipStreamWaitEvent(s, engs[k]->ws[0].ev_join, 0));
+    HIP_TRY(hipEventRecord(e0->ws[0].ev_done, s));           // "the call is complete" for the next call and for vrt_trace_status
+    return VRT_OK;
 }
 
 // chunks per device for the lane pipeline
@@ -715,9 +814,7 @@ int trace_host_impl(vrt_engine *e0, const HostCall &c, size_t nrays, ChunkHooks 
 {
     const vrt_options &o = c.opt ? *c.opt : e0->opt;
     // one band per device ...
-    std::vector<vrt_engine *> engs{e0};
-    for (vrt_engine *r : e0->replicas) engs.push_back(r);
-    if (nrays < 64 * engs.size() || nrays <= o.minimum_gpu) engs.resize(1);   // too few rays to be worth spreading
+    std::vector<vrt_engine *> engs = call_engines(e0, nrays, o, false);
     std::vector<size_t> band;
     band_cut(nrays, engs.size(), band);
 
@@ -798,14 +895,22 @@ void host_parallel_for(size_t n, F f)
 
 }  // namespace
 
+struct SceneSrc {                   // what the ray prologue interpolates the ior from, resident on one device
+    void *d_ior = nullptr;          // the ior volume
+    void *d_density = nullptr;      // LUT scenes: the 8-bit volume instead, with its ior table
+    void *d_lut_ior = nullptr;
+};
 struct vrt_scene {
     vrt_engine *engine = nullptr;
     int ior_type = VRT_F32;
     uint32_t N[3] = {0, 0, 0};
-    void *d_ior = nullptr;          // the ior volume stays resident for the ray prologue's interpolation
-    void *d_density = nullptr;      // LUT scenes: the 8-bit volume stays resident instead, with its ior table
-    void *d_lut_ior = nullptr;
+    std::vector<SceneSrc> src;      // [0] on the primary device, [k] on the device of engine->replicas[k - 1]
     bool device_call_pending = false;   // a vrt_scene_trace_device call whose error words have not been looked at yet
+    const SceneSrc &source_of(const vrt_engine *e) const
+    {
+        for (size_t k = 0; k < engine->replicas.size(); ++k) if (engine->replicas[k] == e && k + 1 < src.size()) return src[k + 1];
+        return src[0];
+    }
 };
 
 // =============================================================================================
@@ -865,25 +970,25 @@ __global__ __launch_bounds__(256) void k_selftest_stage_division(unsigned long l
     if ((threadIdx.x & 63u) == 0) { atomicAdd(&out[0], bad); atomicAdd(&out[1], n_checked); }
 }
 
-// Devices a new handle spans: vrt_options.devices is a bit mask of HIP ordinals (0 = just vrt_options.device, -1 = every
-// visible device).  The first device of the list owns the handle's primary engine.  VRT_DEBUG_REPLICAS=n (tests on a
-// one-GPU box) makes n engines on the primary device instead, so that the band cut and the merge run without peers.
+// Devices a new handle spans: vrt_options.devices is a bit mask of HIP ordinals (0 = just the primary, -1 = every visible
+// device); the primary (vrt_options.device, or the caller's current device) comes first.  VRT_DEBUG_REPLICAS=n (tests on a
+// one-GPU box) turns a handle that would have a single device into n engines on that device, so that the band cut, the
+// fork / join of the streams and the merge run without peers.
 std::vector<int> handle_devices(const vrt_options &o, int primary, int ndev)
 {
-    std::vector<int> devs;
-    if (const char *ev = getenv("VRT_DEBUG_REPLICAS"); ev && atoi(ev) > 1 && o.devices == 0) {
-        devs.assign((size_t)std::min(atoi(ev), 16), primary);
-        return devs;
-    }
-    devs.push_back(primary);
+    std::vector<int> devs{primary};
     if (o.devices != 0)
         for (int d = 0; d < ndev && d < 32; ++d)
             if (d != primary && ((uint32_t)o.devices >> d & 1u)) devs.push_back(d);
+    if (const char *ev = getenv("VRT_DEBUG_REPLICAS"); ev && atoi(ev) > 1 && devs.size() == 1)
+        devs.assign((size_t)std::min(atoi(ev), 16), primary);
     return devs;
 }
 
 // Replicate a finished engine's field (and translucency) onto the other devices of the handle, as the reference's
-// constructor does with cudaMemcpy from the host copy (cuda_volume_raytracer.cu:676-686) -- here device to device.
+// constructor does with cudaMemcpy from the host copy (cuda_volume_raytracer.cu:676-686) -- here device to device, and to
+// all peers at once: every copy is issued on its destination's stream before any of them is waited for, so the 7 xGMI links
+// of the primary carry the 7 copies side by side instead of one after the other.
 int engine_replicate(vrt_engine *e)
 {
     int ndev = 0;
@@ -906,8 +1011,14 @@ int engine_replicate(vrt_engine *e)
         r->field_flags = e->field_flags;
         hipStream_t s = r->ws[0].stream;
         if (r->device != e->device) {
+            // both directions: the replica reads the primary's memory (field copy, the caller's ray arrays of device-pointer
+            // calls) and the primary's streams wait on the replica's events
             int can = 0;
-            if (hipDeviceCanAccessPeer(&can, r->device, e->device) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(e->device, 0);
+            r->peer_ok = hipDeviceCanAccessPeer(&can, r->device, e->device) == hipSuccess && can != 0;
+            if (r->peer_ok) {
+                const hipError_t pe = hipDeviceEnablePeerAccess(e->device, 0);
+                r->peer_ok = pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled;
+            }
             (void)hipGetLastError();                     // "already enabled" is fine
             HIP_TRY(hipMemcpyPeerAsync(r->field, r->device, e->field, e->device, e->field_bytes, s));
         } else {
@@ -918,8 +1029,23 @@ int engine_replicate(vrt_engine *e)
             if (r->device != e->device) HIP_TRY(hipMemcpyPeerAsync(r->transl.p, r->device, e->transl.p, e->device, e->nvox * 4, s));
             else HIP_TRY(hipMemcpyAsync(r->transl.p, e->transl.p, e->nvox * 4, hipMemcpyDeviceToDevice, s));
         }
-        HIP_TRY(hipStreamSynchronize(s));
     }
+    for (vrt_engine *r : e->replicas) {                  // all copies are in flight: now wait for them
+        DeviceGuard g(r->device);
+        HIP_TRY(hipStreamSynchronize(r->ws[0].stream));
+    }
+    return VRT_OK;
+}
+
+// copy `bytes` of device memory of engine `from` into a fresh allocation on engine `to`'s device (scene sources)
+int replicate_buffer(vrt_engine *from, vrt_engine *to, const void *src, size_t bytes, void **out)
+{
+    *out = nullptr;
+    if (!src) return VRT_OK;
+    DeviceGuard g(to->device);
+    HIP_TRY(hipMalloc(out, bytes));
+    if (to->device != from->device) HIP_TRY(hipMemcpyPeerAsync(*out, to->device, src, from->device, bytes, to->ws[0].stream));
+    else HIP_TRY(hipMemcpyAsync(*out, src, bytes, hipMemcpyDeviceToDevice, to->ws[0].stream));
     return VRT_OK;
 }
 
@@ -1032,8 +1158,8 @@ int vrt_trace_device(vrt_handle h, int dir_type, size_t nrays, const uint32_t *d
     DeviceGuard g(h->device);
     std::lock_guard<std::mutex> lock(h->mu);
     // min_brightness is ignored unless the opt-in absorption mode is on, as in the reference (.cu:785)
-    return trace_device_impl(h, h->ws[0], dir_type, nrays, d_sp, d_sd, d_ep, d_ed, d_ei, d_rl, d_path, invscale, iterations,
-                             (hipStream_t)stream, opt, 0, min_brightness);
+    return trace_device_multi(call_engines(h, nrays, opt ? *opt : h->opt, true), dir_type, nrays, d_sp, d_sd, d_ep, d_ed, d_ei, d_rl,
+                              d_path, invscale, iterations, (hipStream_t)stream, opt, 0, min_brightness);
 }
 
 int vrt_trace(vrt_handle h, int dir_type, size_t nrays, const uint32_t *sp, const void *sd, uint32_t *ep, void *ed,
@@ -1111,6 +1237,7 @@ static int scene_create_impl(vrt_scene_handle *out, int dim, const size_t *bound
     vrt_scene *sc = new (std::nothrow) vrt_scene();
     if (!sc) { engine_free(e); return fail(VRT_ERR_OUT_OF_MEMORY, "host allocation failed"); }
     sc->engine = e;
+    sc->src.resize(1);
     sc->ior_type = ior_type;
     for (int d = 0; d < 3; ++d) sc->N[d] = (uint32_t)bounds[d];
     void *d_lg = nullptr, *d_tr = nullptr, *d_err = nullptr;
@@ -1129,14 +1256,14 @@ static int scene_create_impl(vrt_scene_handle *out, int dim, const size_t *bound
         hipMalloc(&d_err, sizeof(vrt::SceneErr)) != hipSuccess)
         return cleanup(fail(VRT_ERR_OUT_OF_MEMORY, "device allocation failed"));
     if (density) {
-        if (hipMalloc(&sc->d_density, nvox) != hipSuccess || hipMalloc(&sc->d_lut_ior, 256 * 4) != hipSuccess)
+        if (hipMalloc(&sc->src[0].d_density, nvox) != hipSuccess || hipMalloc(&sc->src[0].d_lut_ior, 256 * 4) != hipSuccess)
             return cleanup(fail(VRT_ERR_OUT_OF_MEMORY, "device allocation failed"));
-        if (hipMemcpyAsync(sc->d_density, density, nvox, hipMemcpyHostToDevice, s) != hipSuccess ||
-            hipMemcpyAsync(sc->d_lut_ior, ior, 256 * 4, hipMemcpyHostToDevice, s) != hipSuccess)
+        if (hipMemcpyAsync(sc->src[0].d_density, density, nvox, hipMemcpyHostToDevice, s) != hipSuccess ||
+            hipMemcpyAsync(sc->src[0].d_lut_ior, ior, 256 * 4, hipMemcpyHostToDevice, s) != hipSuccess)
             return cleanup(fail(VRT_ERR_HIP, "scene upload failed"));
     } else {
-        if (hipMalloc(&sc->d_ior, nvox * 4) != hipSuccess) return cleanup(fail(VRT_ERR_OUT_OF_MEMORY, "device allocation failed"));
-        if (hipMemcpyAsync(sc->d_ior, ior, nvox * 4, hipMemcpyHostToDevice, s) != hipSuccess)
+        if (hipMalloc(&sc->src[0].d_ior, nvox * 4) != hipSuccess) return cleanup(fail(VRT_ERR_OUT_OF_MEMORY, "device allocation failed"));
+        if (hipMemcpyAsync(sc->src[0].d_ior, ior, nvox * 4, hipMemcpyHostToDevice, s) != hipSuccess)
             return cleanup(fail(VRT_ERR_HIP, "scene upload failed"));
     }
     if (hipMemcpyAsync(d_lg, lg.data(), ntab * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
@@ -1148,38 +1275,75 @@ static int scene_create_impl(vrt_scene_handle *out, int dim, const size_t *bound
         if (e->transl.reserve(fvox * 4) != hipSuccess) return cleanup(fail(VRT_ERR_OUT_OF_MEMORY, "device allocation failed"));
         d_tc = (uint32_t *)e->transl.p;
     }
-    const unsigned grid = (unsigned)((fvox + 255) / 256);
     vrt::SceneErr *derr = (vrt::SceneErr *)d_err;
-    const uint8_t *dd = (const uint8_t *)sc->d_density;
+    const uint8_t *dd = (const uint8_t *)sc->src[0].d_density;
+    // LDS-tiled build with the field scan fused in (vrt_scene.h); VRT_SCENE_BUILD=pervoxel selects the round-2 kernel
+    // (one thread per voxel, 27 global loads) for A/B runs and for the test that holds the two to the same bits
+    bool tiled = true;
+    if (const char *ev = getenv("VRT_SCENE_BUILD")) tiled = strcmp(ev, "pervoxel") != 0;
+    const dim3 tgrid((sc->N[2] - 2 + vrt::kTZ - 1) / vrt::kTZ, (sc->N[1] - 2 + vrt::kTY - 1) / vrt::kTY, (sc->N[0] - 2 + vrt::kXS - 1) / vrt::kXS);
+    const size_t nwg = (size_t)tgrid.x * tgrid.y * tgrid.z;
+    const unsigned grid = (unsigned)((fvox + 255) / 256);
+    void *d_part = nullptr;
+    if (tiled && (tgrid.y > 65535u || tgrid.z > 65535u)) tiled = false;
+    if (tiled && hipMalloc(&d_part, (nwg + 1) * 5 * sizeof(uint32_t)) != hipSuccess) return cleanup(fail(VRT_ERR_OUT_OF_MEMORY, "device allocation failed"));
+    uint32_t *part = (uint32_t *)d_part;
     Range range("vrt: scene build");
+#define VRT_BUILD(LOGSRC, TRSRC, VOX)                                                                                        \
+    do {                                                                                                                     \
+        if (tiled) vrt::k_scene_build_tiled<<<tgrid, vrt::kTY * vrt::kTZ, 0, s>>>(LOGSRC, TRSRC, sc->N[0], sc->N[1], sc->N[2], (VOX *)e->field, derr, d_tc, part); \
+        else       vrt::k_scene_build<<<grid, 256, 0, s>>>(LOGSRC, TRSRC, sc->N[0], sc->N[1], sc->N[2], (VOX *)e->field, derr, d_tc);          \
+    } while (0)
     if (ior_type == VRT_F32) {
-        if (density)
-            vrt::k_scene_build<<<grid, 256, 0, s>>>(vrt::SrcLut<float>{dd, (const float *)d_lg}, vrt::SrcLut<uint32_t>{dd, (const uint32_t *)d_tr},
-                                                    sc->N[0], sc->N[1], sc->N[2], (vrt::vox_f32 *)e->field, derr, d_tc);
-        else
-            vrt::k_scene_build<<<grid, 256, 0, s>>>(vrt::SrcArray<float>{(const float *)d_lg}, vrt::SrcArray<uint32_t>{(const uint32_t *)d_tr},
-                                                    sc->N[0], sc->N[1], sc->N[2], (vrt::vox_f32 *)e->field, derr, d_tc);
+        if (density) VRT_BUILD((vrt::SrcLut<float>{dd, (const float *)d_lg}), (vrt::SrcLut<uint32_t>{dd, (const uint32_t *)d_tr}), vrt::vox_f32);
+        else         VRT_BUILD((vrt::SrcArray<float>{(const float *)d_lg}), (vrt::SrcArray<uint32_t>{(const uint32_t *)d_tr}), vrt::vox_f32);
     } else {
-        if (density)
-            vrt::k_scene_build<<<grid, 256, 0, s>>>(vrt::SrcLut<int32_t>{dd, (const int32_t *)d_lg}, vrt::SrcLut<uint32_t>{dd, (const uint32_t *)d_tr},
-                                                    sc->N[0], sc->N[1], sc->N[2], (vrt::vox_i16 *)e->field, derr, d_tc);
-        else
-            vrt::k_scene_build<<<grid, 256, 0, s>>>(vrt::SrcArray<int32_t>{(const int32_t *)d_lg}, vrt::SrcArray<uint32_t>{(const uint32_t *)d_tr},
-                                                    sc->N[0], sc->N[1], sc->N[2], (vrt::vox_i16 *)e->field, derr, d_tc);
+        if (density) VRT_BUILD((vrt::SrcLut<int32_t>{dd, (const int32_t *)d_lg}), (vrt::SrcLut<uint32_t>{dd, (const uint32_t *)d_tr}), vrt::vox_i16);
+        else         VRT_BUILD((vrt::SrcArray<int32_t>{(const int32_t *)d_lg}), (vrt::SrcArray<uint32_t>{(const uint32_t *)d_tr}), vrt::vox_i16);
     }
-    if (const hipError_t le = hipGetLastError(); le != hipSuccess)
+#undef VRT_BUILD
+    if (const hipError_t le = hipGetLastError(); le != hipSuccess) {
+        if (d_part) (void)hipFree(d_part);
         return cleanup(fail(VRT_ERR_HIP, "scene build launch failed: %s", hipGetErrorString(le)));
+    }
+    uint32_t habs[5] = {0, 0, 0, 0, 0};
+    hipError_t be = hipSuccess;
+    if (tiled) {
+        be = hipMemsetAsync(part + nwg * 5, 0, 5 * sizeof(uint32_t), s);
+        const unsigned rgrid = (unsigned)std::min<size_t>((nwg + 255) / 256, 128);
+        if (be == hipSuccess) { vrt::k_absmax_reduce<<<rgrid, 256, 0, s>>>(part, nwg, part + nwg * 5); be = hipGetLastError(); }
+        if (be == hipSuccess) be = hipMemcpyAsync(habs, part + nwg * 5, sizeof habs, hipMemcpyDeviceToHost, s);
+    }
     vrt::SceneErr herr;
-    hipError_t be = hipMemcpyAsync(&herr, d_err, sizeof herr, hipMemcpyDeviceToHost, s);
+    if (be == hipSuccess) be = hipMemcpyAsync(&herr, d_err, sizeof herr, hipMemcpyDeviceToHost, s);
     if (be == hipSuccess) be = hipStreamSynchronize(s);
+    if (d_part) (void)hipFree(d_part);
     if (be != hipSuccess) return cleanup(fail(VRT_ERR_HIP, "scene build failed: %s", hipGetErrorString(be)));
     if (herr.diff_overflow) return cleanup(fail(VRT_ERR_SCENE, "differention overflow"));          // image_util.cpp:291-293
-    rc = engine_field_absmax(e, s);
+    if (tiled) engine_apply_absmax(e, habs);
+    else rc = engine_field_absmax(e, s);
     if (rc) return cleanup(rc);
     (void)hipFree(d_lg);
     (void)hipFree(d_tr);
     (void)hipFree(d_err);
     d_lg = d_tr = d_err = nullptr;
+    // a scene over several devices (vrt_options.devices): the field and what the ray prologue reads, on every one of them
+    // (RaytraceScene constructs its TraceRaysCu over all CUDA devices, image_util.cpp:561 -> cuda_volume_raytracer.cu:676-686)
+    rc = engine_replicate(e);
+    if (rc) return cleanup(rc);
+    sc->src.resize(1 + e->replicas.size());
+    for (size_t k = 0; k < e->replicas.size() && !rc; ++k) {
+        vrt_engine *r = e->replicas[k];
+        SceneSrc &dst = sc->src[k + 1];
+        rc = replicate_buffer(e, r, sc->src[0].d_ior, nvox * 4, &dst.d_ior);
+        if (!rc) rc = replicate_buffer(e, r, sc->src[0].d_density, nvox, &dst.d_density);
+        if (!rc) rc = replicate_buffer(e, r, sc->src[0].d_lut_ior, 256 * 4, &dst.d_lut_ior);
+    }
+    for (vrt_engine *r : e->replicas) {
+        DeviceGuard gr(r->device);
+        if (hipStreamSynchronize(r->ws[0].stream) != hipSuccess && !rc) rc = fail(VRT_ERR_HIP, "scene replication failed");
+    }
+    if (rc) return cleanup(rc);
     *out = sc;
     return VRT_OK;
 }
@@ -1204,30 +1368,42 @@ namespace {
 // The scene layer's ray front end (RaytraceScene::trace_rays, image_util.cpp:673-722) as chunk hooks: the prologue
 // kernel rewrites the start arrays in place on the chunk's stream, the march follows without any host round trip, and
 // the error words (range check, normalisation overflow) come back with the results and are looked at afterwards.
-int scene_prologue(vrt_scene *sc, Workspace &w, int dir_type, const uint32_t *d_pos_in, const void *d_dir_in,
-                   uint32_t *d_pos_out, void *d_dir_out, size_t n, hipStream_t s)
+// `sticky`: the error words are the lane's accumulating set (device-pointer calls: kept over calls until
+// vrt_scene_trace_status reads them) instead of the per-call set that travels back through pinned memory (host-pointer calls).
+int scene_prologue(vrt_scene *sc, const SceneSrc &src, Workspace &w, int dir_type, const uint32_t *d_pos_in, const void *d_dir_in,
+                   uint32_t *d_pos_out, void *d_dir_out, size_t n, hipStream_t s, bool sticky)
 {
-    HIP_TRY(w.err.reserve(sizeof(vrt::SceneErr)));
-    if (!w.pin_err) HIP_TRY(hipHostMalloc(&w.pin_err, sizeof(vrt::SceneErr), hipHostMallocDefault));
-    HIP_TRY(hipMemsetAsync(w.err.p, 0, sizeof(vrt::SceneErr), s));
-    HIP_TRY(hipMemsetAsync((char *)w.err.p + offsetof(vrt::SceneErr, first_bad_ray), 0xFF, 4, s));
+    vrt::SceneErr *derr = nullptr;
+    if (sticky) {
+        if (!w.err_sticky.p) {
+            HIP_TRY(w.err_sticky.reserve(sizeof(vrt::SceneErr)));
+            HIP_TRY(hipMemsetAsync(w.err_sticky.p, 0, sizeof(vrt::SceneErr), s));
+            HIP_TRY(hipMemsetAsync((char *)w.err_sticky.p + offsetof(vrt::SceneErr, first_bad_ray), 0xFF, 4, s));
+        }
+        derr = (vrt::SceneErr *)w.err_sticky.p;
+    } else {
+        HIP_TRY(w.err.reserve(sizeof(vrt::SceneErr)));
+        if (!w.pin_err) HIP_TRY(hipHostMalloc(&w.pin_err, sizeof(vrt::SceneErr), hipHostMallocDefault));
+        HIP_TRY(hipMemsetAsync(w.err.p, 0, sizeof(vrt::SceneErr), s));
+        HIP_TRY(hipMemsetAsync((char *)w.err.p + offsetof(vrt::SceneErr, first_bad_ray), 0xFF, 4, s));
+        derr = (vrt::SceneErr *)w.err.p;
+    }
     const unsigned grid = (unsigned)((n + 255) / 256);
-    vrt::SceneErr *derr = (vrt::SceneErr *)w.err.p;
-    const uint8_t *dd = (const uint8_t *)sc->d_density;
+    const uint8_t *dd = (const uint8_t *)src.d_density;
     Range range("vrt: ray prologue");
     if (dir_type == VRT_F32) {
-        if (dd) vrt::k_ray_prologue<<<grid, 256, 0, s>>>(vrt::SrcLut<float>{dd, (const float *)sc->d_lut_ior}, sc->N[0], sc->N[1], sc->N[2], d_pos_in,
+        if (dd) vrt::k_ray_prologue<<<grid, 256, 0, s>>>(vrt::SrcLut<float>{dd, (const float *)src.d_lut_ior}, sc->N[0], sc->N[1], sc->N[2], d_pos_in,
                                                          (const float *)d_dir_in, d_pos_out, (float *)d_dir_out, (uint32_t)n, derr);
-        else    vrt::k_ray_prologue<<<grid, 256, 0, s>>>(vrt::SrcArray<float>{(const float *)sc->d_ior}, sc->N[0], sc->N[1], sc->N[2], d_pos_in,
+        else    vrt::k_ray_prologue<<<grid, 256, 0, s>>>(vrt::SrcArray<float>{(const float *)src.d_ior}, sc->N[0], sc->N[1], sc->N[2], d_pos_in,
                                                          (const float *)d_dir_in, d_pos_out, (float *)d_dir_out, (uint32_t)n, derr);
     } else {
-        if (dd) vrt::k_ray_prologue<<<grid, 256, 0, s>>>(vrt::SrcLut<uint32_t>{dd, (const uint32_t *)sc->d_lut_ior}, sc->N[0], sc->N[1], sc->N[2], d_pos_in,
+        if (dd) vrt::k_ray_prologue<<<grid, 256, 0, s>>>(vrt::SrcLut<uint32_t>{dd, (const uint32_t *)src.d_lut_ior}, sc->N[0], sc->N[1], sc->N[2], d_pos_in,
                                                          (const int16_t *)d_dir_in, d_pos_out, (int16_t *)d_dir_out, (uint32_t)n, derr);
-        else    vrt::k_ray_prologue<<<grid, 256, 0, s>>>(vrt::SrcArray<uint32_t>{(const uint32_t *)sc->d_ior}, sc->N[0], sc->N[1], sc->N[2], d_pos_in,
+        else    vrt::k_ray_prologue<<<grid, 256, 0, s>>>(vrt::SrcArray<uint32_t>{(const uint32_t *)src.d_ior}, sc->N[0], sc->N[1], sc->N[2], d_pos_in,
                                                          (const int16_t *)d_dir_in, d_pos_out, (int16_t *)d_dir_out, (uint32_t)n, derr);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(w.pin_err, w.err.p, sizeof(vrt::SceneErr), hipMemcpyDeviceToHost, s));   // pinned: truly asynchronous
+    if (!sticky) HIP_TRY(hipMemcpyAsync(w.pin_err, w.err.p, sizeof(vrt::SceneErr), hipMemcpyDeviceToHost, s));   // pinned: truly asynchronous
     return VRT_OK;
 }
 
@@ -1237,9 +1413,9 @@ struct SceneHooks : ChunkHooks {
     std::atomic<unsigned long long> first_bad{~0ull};
     std::atomic<int> normalize_overflow{0};
     SceneHooks(vrt_scene *s, int dt) : sc(s), dir_type(dt) {}
-    int pre(vrt_engine *, Workspace &w, uint32_t *d_pos, void *d_dir, size_t n, size_t, hipStream_t s) override
+    int pre(vrt_engine *e, Workspace &w, uint32_t *d_pos, void *d_dir, size_t n, size_t, hipStream_t s) override
     {
-        return scene_prologue(sc, w, dir_type, d_pos, d_dir, d_pos, d_dir, n, s);
+        return scene_prologue(sc, sc->source_of(e), w, dir_type, d_pos, d_dir, d_pos, d_dir, n, s, false);
     }
     int post(vrt_engine *, Workspace &w, size_t, size_t off) override
     {
@@ -1279,6 +1455,28 @@ int vrt_scene_trace(vrt_scene_handle sc, int dir_type, size_t nrays, const uint3
     rc = scene_check_trace_args(sc, dir_type);
     if (rc) return rc;
     if (nrays == 0) return VRT_OK;
+    {   // the range check first and on the host, as the reference does it (image_util.cpp:673-697 throws before anything is
+        // traced, so the outputs stay untouched); the device prologue repeats it for the device-pointer entry point
+        std::atomic<unsigned long long> first_bad{~0ull};
+        const unsigned long long lim[3] = {(unsigned long long)sc->N[0] * 0x10000ull, (unsigned long long)sc->N[1] * 0x10000ull,
+                                           (unsigned long long)sc->N[2] * 0x10000ull};
+        host_parallel_for(nrays, [&](size_t b, size_t e2) {
+            for (size_t i = b; i < e2; ++i) {
+                bool bad = false;
+                for (int d = 0; d < 3; ++d) bad |= sp[3 * i + d] < 0x10000u || (unsigned long long)sp[3 * i + d] + 1ull >= lim[d];
+                if (bad) {
+                    unsigned long long cur = first_bad.load();
+                    while (i < cur && !first_bad.compare_exchange_weak(cur, i)) {}
+                    return;                                     // this slice's first bad ray is its lowest
+                }
+            }
+        });
+        if (first_bad.load() != ~0ull) {
+            const size_t i = (size_t)first_bad.load();
+            return fail(VRT_ERR_RAY_RANGE, "ray %zu:%g %g %g is not in 0 to %u %u %u", i, sp[3 * i] / 65536.0,
+                        sp[3 * i + 1] / 65536.0, sp[3 * i + 2] / 65536.0, sc->N[0], sc->N[1], sc->N[2]);
+        }
+    }
     DeviceGuard g(e->device);
     std::lock_guard<std::mutex> lock(e->mu);
     const HostCall c{dir_type, sp, sd, ep, ed, ei, rl, path, invscale, iterations, min_brightness, 0x10000u, opt};
@@ -1314,38 +1512,50 @@ int vrt_scene_trace_device(vrt_scene_handle sc, int dir_type, size_t nrays, cons
     if (w.used) HIP_TRY(hipStreamWaitEvent(s, w.ev_done, 0));      // the prologue buffers below belong to the lane too
     HIP_TRY(w.pro_pos.reserve(nrays * 12));
     HIP_TRY(w.pro_dir.reserve(nrays * 3 * dsz));
-    rc = scene_prologue(sc, w, dir_type, d_sp, d_sd, (uint32_t *)w.pro_pos.p, w.pro_dir.p, nrays, s);
+    // the prologue is O(rays) and runs on the primary device for all of them; the bands of a multi-device scene then read
+    // its output through peer access like any other device-resident start arrays
+    rc = scene_prologue(sc, sc->src[0], w, dir_type, d_sp, d_sd, (uint32_t *)w.pro_pos.p, w.pro_dir.p, nrays, s, true);
     if (rc) return rc;
     sc->device_call_pending = true;
-    return trace_device_impl(e, w, dir_type, nrays, (const uint32_t *)w.pro_pos.p, w.pro_dir.p, d_ep, d_ed, d_ei, d_rl, d_path,
-                             invscale, iterations, s, opt, 0x10000u, min_brightness);
+    return trace_device_multi(call_engines(e, nrays, opt ? *opt : e->opt, true), dir_type, nrays, (const uint32_t *)w.pro_pos.p,
+                              w.pro_dir.p, d_ep, d_ed, d_ei, d_rl, d_path, invscale, iterations, s, opt, 0x10000u, min_brightness);
 }
 
 int vrt_scene_trace_status(vrt_scene_handle sc)
 {
     if (!sc) return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_scene_trace_status: NULL scene");
-    if (!sc->device_call_pending) return VRT_OK;
     vrt_engine *e = sc->engine;
     DeviceGuard g(e->device);
-    std::lock_guard<std::mutex> lock(e->mu);
-    Workspace &w = e->ws[0];
-    HIP_TRY(hipEventSynchronize(w.ev_done));
-    sc->device_call_pending = false;
-    const vrt::SceneErr *h = (const vrt::SceneErr *)w.pin_err;
-    if (h->first_bad_ray != 0xFFFFFFFFu)
-        return fail(VRT_ERR_RAY_RANGE, "ray %u is not in 0 to %u %u %u", h->first_bad_ray, sc->N[0], sc->N[1], sc->N[2]);
-    if (h->normalize_overflow) return fail(VRT_ERR_SCENE, "Normalize length failed: -32768<=tmp<=32767");
-    return VRT_OK;
+    vrt::SceneErr h{0u, 0xFFFFFFFFu, 0u};
+    {
+        std::lock_guard<std::mutex> lock(e->mu);
+        if (!sc->device_call_pending) return VRT_OK;
+        Workspace &w = e->ws[0];
+        HIP_TRY(hipEventSynchronize(w.ev_done));
+        sc->device_call_pending = false;
+        if (w.err_sticky.p) {
+            // the accumulated error words of every device-pointer call since the last status call (lowest bad ray index of
+            // any of them), then cleared
+            HIP_TRY(hipMemcpy(&h, w.err_sticky.p, sizeof h, hipMemcpyDeviceToHost));
+            const vrt::SceneErr clear{0u, 0xFFFFFFFFu, 0u};
+            HIP_TRY(hipMemcpy(w.err_sticky.p, &clear, sizeof clear, hipMemcpyHostToDevice));
+        }
+    }
+    if (h.first_bad_ray != 0xFFFFFFFFu)
+        return fail(VRT_ERR_RAY_RANGE, "ray %u is not in 0 to %u %u %u", h.first_bad_ray, sc->N[0], sc->N[1], sc->N[2]);
+    if (h.normalize_overflow) return fail(VRT_ERR_SCENE, "Normalize length failed: -32768<=tmp<=32767");
+    return vrt_trace_status(e);                                     // scheduler errors of the march itself
 }
 
 void vrt_scene_destroy(vrt_scene_handle sc)
 {
     if (!sc) return;
     if (sc->engine) {
-        DeviceGuard g(sc->engine->device);
-        if (sc->d_ior) (void)hipFree(sc->d_ior);
-        if (sc->d_density) (void)hipFree(sc->d_density);
-        if (sc->d_lut_ior) (void)hipFree(sc->d_lut_ior);
+        for (size_t k = 0; k < sc->src.size(); ++k) {
+            const vrt_engine *owner = k == 0 ? sc->engine : (k - 1 < sc->engine->replicas.size() ? sc->engine->replicas[k - 1] : sc->engine);
+            DeviceGuard g(owner->device);
+            for (void *q : {sc->src[k].d_ior, sc->src[k].d_density, sc->src[k].d_lut_ior}) if (q) (void)hipFree(q);
+        }
         engine_free(sc->engine);
     }
     delete sc;
@@ -1361,6 +1571,47 @@ const void *vrt_engine_field_device_ptr(vrt_handle h) { return h ? h->field : nu
 
 int vrt_engine_replica_count(vrt_handle h) { return h ? 1 + (int)h->replicas.size() : 0; }
 
+int vrt_engine_last_schedule(vrt_handle h) { return h ? h->ws[0].last_schedule : 0; }
+
+int vrt_engine_download_field(vrt_handle h, void *dst, size_t bytes)
+{
+    if (!h || !dst) return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_engine_download_field: NULL argument");
+    if (bytes > h->field_bytes) return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_engine_download_field: %zu bytes asked, the field has %zu", bytes, h->field_bytes);
+    DeviceGuard g(h->device);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(dst, h->field, bytes, hipMemcpyDeviceToHost));
+    return VRT_OK;
+}
+
+int vrt_engine_field_scan(vrt_handle h, float *bounds4, uint32_t *flags)
+{
+    if (!h || !bounds4 || !flags) return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_engine_field_scan: NULL argument");
+    for (int d = 0; d < 3; ++d) bounds4[d] = h->gmax[d];
+    bounds4[3] = h->gnorm;
+    *flags = h->field_flags;
+    return VRT_OK;
+}
+
+int vrt_trace_status(vrt_handle h)
+{
+    if (!h) return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_trace_status: NULL handle");
+    std::lock_guard<std::mutex> lock(h->mu);
+    std::vector<vrt_engine *> engs{h};
+    for (vrt_engine *r : h->replicas) engs.push_back(r);
+    uint32_t gave_up = 0;
+    for (vrt_engine *e : engs) {
+        DeviceGuard g(e->device);
+        for (Workspace &w : e->ws) {
+            if (!w.used) continue;
+            HIP_TRY(hipEventSynchronize(w.ev_done));
+            gave_up += *(volatile uint32_t *)w.pin_sched_err;
+            *w.pin_sched_err = 0u;
+        }
+    }
+    if (gave_up) return fail(VRT_ERR_HIP, "time-sliced schedule: a wavefront gave up waiting (%u); results are incomplete", gave_up);
+    return VRT_OK;
+}
+
 int vrt_engine_debug_stats(vrt_handle h, unsigned long long *out, int n)
 {
     if (!h || !out || n <= 0) return fail(VRT_ERR_INVALID_ARGUMENT, "vrt_engine_debug_stats: bad argument");
@@ -1370,9 +1621,9 @@ int vrt_engine_debug_stats(vrt_handle h, unsigned long long *out, int n)
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, w.stats.p, sizeof(unsigned long long) * std::min((size_t)n, w.stats_count), hipMemcpyDeviceToHost));
     if (n >= 64 && w.group_ctr.p) {                        // scheduler words of the last launch: tickets, groups finished, error
-        uint32_t c[4] = {0, 0, 0, 0};
+        uint32_t c[vrt::kCtrWords] = {0};
         HIP_TRY(hipMemcpy(c, w.group_ctr.p, std::min<size_t>(sizeof c, w.group_ctr.cap), hipMemcpyDeviceToHost));
-        for (int k = 0; k < 4; ++k) out[60 + k] = c[k];
+        for (int k = 0; k < 4; ++k) out[60 + k] = c[k * vrt::kCtrStride];
     }
     return VRT_OK;
 }

@@ -48,6 +48,8 @@ struct MarchParams {
     uint32_t work_unit;       // fine steps per unit of that estimate (kCoarse)
     uint32_t slice_percent;   // slice = mean estimated wave-steps per wavefront x this / 100
     uint32_t ticket_limit;    // time-sliced schedule only: words in the FIFO ring (a power of two >= 2 x groups)
+    uint32_t spin_limit;      // time-sliced schedule only: polls after which a waiting wavefront gives up and raises the error words
+    uint32_t *sched_err;      // time-sliced schedule only: error word in pinned host memory (device address), written on that path only
     uint32_t out_pos_bias;    // added to end_pos / path on output: 0 at the seam, 0x10000 for the scene
                               // layer's "+0x10000" epilogue (image_util.cpp:770-771)
     unsigned long long *clock_out; // optional: 4 words {s_memtime, s_memrealtime} x {begin, end} of one wavefront (wave 0 of block 0)

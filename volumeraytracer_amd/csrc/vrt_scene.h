@@ -13,6 +13,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "vrt_march.h"
 
@@ -29,14 +30,39 @@ __device__ __forceinline__ int stamp_m(int a, int b)
 // Voxel sources: a plain array, or an 8-bit density volume seen through a 256-entry table
 // (BASELINE config 5 / SURVEY row f-3, reading A: the table is expanded on the fly, so the stencil and
 // the ior interpolation see exactly the arrays the reference would be given).
+// Two-phase form for the tiled build: raw(i) is the element as it lies in memory (issued a plane ahead), cook(raw, table)
+// turns it into the value -- for a LUT source a look-up in the workgroup's LDS copy of the 256-entry table, so that no
+// global load ever depends on another one.
 template <typename T> struct SrcArray {
     const T *a;
+    using raw_t = T;
+    static constexpr bool kLut = false;
     __device__ __forceinline__ T operator()(size_t i) const { return a[i]; }
+    __device__ __forceinline__ raw_t raw(size_t i) const { return a[i]; }
+    __device__ __forceinline__ T cook(raw_t r, const uint32_t *) const { return r; }
+    __device__ __forceinline__ uint32_t table_bits(uint32_t) const { return 0u; }
 };
 template <typename T> struct SrcLut {
     const uint8_t *d;
     const T *lut;
+    using raw_t = uint8_t;
+    static constexpr bool kLut = true;
     __device__ __forceinline__ T operator()(size_t i) const { return lut[d[i]]; }
+    __device__ __forceinline__ raw_t raw(size_t i) const { return d[i]; }
+    __device__ __forceinline__ T cook(raw_t r, const uint32_t *table) const
+    {
+        const uint32_t b = table[r];
+        T v;
+        __builtin_memcpy(&v, &b, 4);
+        return v;
+    }
+    __device__ __forceinline__ uint32_t table_bits(uint32_t k) const
+    {
+        const T v = lut[k];
+        uint32_t b;
+        __builtin_memcpy(&b, &v, 4);
+        return b;
+    }
 };
 
 struct SceneErr {            // device -> host error words
@@ -112,6 +138,201 @@ __global__ __launch_bounds__(256) void k_scene_build(const LogSrc lg, const TrSr
         v.w = (int16_t)((int32_t)(0x7FFFFFFFu - tr) / 0x10000);
         field[idx] = v;
         if (transl_cropped) transl_cropped[idx] = tr;
+    }
+}
+
+// ---- LDS-tiled scene build (round 3) ---------------------------------------------------------------------------
+// The per-voxel kernel above reads its 27 taps straight from global memory: 27 poorly coalesced loads per voxel (or 27
+// byte loads + table look-ups for a LUT scene) kept it at 0.37 of the HBM peak at 512^3 and 0.12 at 1024^3 + LUT
+// (profiles/r02_scene_build_512.txt).  Here a workgroup owns a column of kTY x kTZ output voxels and walks it along x
+// (the classic 2.5-D stencil): every input plane is staged ONCE per workgroup into LDS as a (kTY + 2) x (kTZ + 2) tile
+// of log values -- rows of 34 consecutive z, i.e. coalesced 136-byte (34-byte for the 8-bit volume) runs; the LUT is applied
+// while staging, one look-up per staged voxel instead of 27 per output -- each thread then reads its 3 x 3 neighbourhood of
+// the new plane from LDS (9 reads per output instead of 27 loads) and keeps the two previous planes in registers.  The
+// plane buffer is double-buffered: one barrier per plane, and the next plane's global loads are in flight during the
+// arithmetic of the current one.  Results are written as 512-byte (256-byte int16) runs along z.
+//
+// The arithmetic is the per-voxel kernel's, term for term: three independent fma chains in ascending stamp index
+// (i major, k minor), zero coefficients skipped (image_util.cpp:401-411), IEEE division by 812 * 256; the integer family
+// wraps in int32 and rounds with divRoundClosest.  tests/test_gpu_scene.py holds both kernels to the reference's bits.
+//
+// The field scan the engine needs for its proven rounds and the prescale flag (engine_field_absmax: max |channel|, max
+// squared gradient length, smallest non-zero magnitude) is fused in: each workgroup reduces its voxels and writes five
+// words; k_absmax_reduce folds them.  (Atomics on five addresses from 16 384 workgroups would serialise, see k_ray_bounds.)
+constexpr int kTY = 8, kTZ = 32, kXS = 32;              // output tile of a workgroup: kXS x kTY x kTZ voxels (x walked)
+
+template <typename LogSrc, typename TrSrc, typename VoxT>
+__global__ __launch_bounds__(kTY * kTZ) void k_scene_build_tiled(const LogSrc lg, const TrSrc transl, uint32_t Nx, uint32_t Ny, uint32_t Nz,
+                                                                  VoxT *__restrict__ field, SceneErr *err,
+                                                                  uint32_t *__restrict__ transl_cropped /* or nullptr */,
+                                                                  uint32_t *__restrict__ absmax_partial /* [workgroups][5] */)
+{
+    constexpr bool kFloat = sizeof(VoxT) == 16;
+    using T = std::conditional_t<kFloat, float, uint32_t>;   // log values: float, or int32 held as uint32 (the sums wrap)
+    constexpr int PY = kTY + 2, PZ = kTZ + 2, kThreads = kTY * kTZ;
+    __shared__ T plane[2][PY][PZ];
+    __shared__ uint32_t tab_lg[LogSrc::kLut ? 256 : 1], tab_tr[TrSrc::kLut ? 256 : 1];   // LUT scenes: the two tables, one look-up per staged voxel
+    if constexpr (LogSrc::kLut) { for (uint32_t k = threadIdx.x; k < 256u; k += kThreads) tab_lg[k] = lg.table_bits(k); }
+    if constexpr (TrSrc::kLut) { for (uint32_t k = threadIdx.x; k < 256u; k += kThreads) tab_tr[k] = transl.table_bits(k); }
+    const uint32_t Ox = Nx - 2, Oy = Ny - 2, Oz = Nz - 2;
+    const uint32_t tid = threadIdx.x, tz = tid % kTZ, ty = tid / kTZ;
+    const uint32_t z0 = blockIdx.x * kTZ, y0 = blockIdx.y * kTY, x0 = blockIdx.z * kXS;
+    const uint32_t y = y0 + ty, z = z0 + tz;
+    const bool active = y < Oy && z < Oz;
+    const uint32_t nx = Ox - x0 < (uint32_t)kXS ? Ox - x0 : (uint32_t)kXS;     // output planes of this workgroup
+    const uint32_t nplanes = nx + 2;
+
+    // staging slots of this thread: the same two tile positions for every plane
+    bool s_ok[2];
+    uint32_t s_ly[2], s_lz[2];
+    size_t s_off[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const uint32_t sidx = tid + kThreads * q;
+        s_ly[q] = sidx / PZ;
+        s_lz[q] = sidx - s_ly[q] * PZ;
+        s_ok[q] = sidx < (uint32_t)(PY * PZ) && y0 + s_ly[q] < Ny && z0 + s_lz[q] < Nz;
+        s_off[q] = (size_t)(y0 + s_ly[q]) * Nz + (z0 + s_lz[q]);
+    }
+    // global loads are issued a plane ahead (gload at the top of an iteration) and consumed at its bottom (lstore) or in the
+    // next iteration (the translucency of the output voxel): their latency lies under the arithmetic of the current plane
+    typename LogSrc::raw_t stage[2] = {};
+    auto gload = [&](uint32_t xin) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) if (s_ok[q]) stage[q] = lg.raw((size_t)xin * Ny * Nz + s_off[q]);
+    };
+    auto lstore = [&](uint32_t b) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) if (s_ok[q]) plane[b][s_ly[q]][s_lz[q]] = (T)lg.cook(stage[q], tab_lg);
+    };
+    typename TrSrc::raw_t tr_raw = {}, tr_next = {};
+    const size_t tr_off = (size_t)(y + 1) * Nz + (z + 1);                // crop_matrix, image_util.cpp:300-319
+
+    T p[3][3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) p[i][j][k] = T(0);
+    uint32_t m[5] = {0u, 0u, 0u, 0u, 0u};                 // the field scan: see k_field_absmax (vrt_engine.hip)
+    bool ovf = false;
+
+    __syncthreads();                                      // the tables
+    gload(x0);
+    lstore(0);
+    __syncthreads();
+    for (uint32_t t = 0; t < nplanes; ++t) {
+        if (t + 1 < nplanes) gload(x0 + t + 1);           // in flight during the arithmetic below
+        if (active && t >= 1 && t - 1 < nx) tr_next = transl.raw((size_t)(x0 + t) * Ny * Nz + tr_off);   // of output plane x0 + t - 1, needed next iteration
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                p[0][j][k] = p[1][j][k];
+                p[1][j][k] = p[2][j][k];
+                p[2][j][k] = plane[t & 1u][ty + j][tz + k];
+            }
+        if (t >= 2 && active) {
+            const uint32_t x = x0 + t - 2;
+            const size_t idx = ((size_t)x * Oy + y) * Oz + z;
+            const uint32_t tr = transl.cook(tr_raw, tab_tr);
+            VoxT o;
+            float a[3];
+            if constexpr (kFloat) {
+                float sum[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const float v = p[i][j][k];
+                            if (i != 1) sum[0] = fma_((float)((i - 1) * stamp_m(j, k)), v, sum[0]);
+                            if (j != 1) sum[1] = fma_((float)((j - 1) * stamp_m(i, k)), v, sum[1]);
+                            if (k != 1) sum[2] = fma_((float)((k - 1) * stamp_m(i, j)), v, sum[2]);
+                        }
+                const float weight = 812.0f * 256.0f;
+                o.x = sum[0] / weight; o.y = sum[1] / weight; o.z = sum[2] / weight;          // "sum /= weight", image_util.cpp:283-285
+                o.w = (float)((int32_t)(0x7FFFFFFFu - tr) / 0x10000);                         // cuda_volume_raytracer.cu:656-659
+                a[0] = o.x; a[1] = o.y; a[2] = o.z;
+            } else {
+                uint32_t sum[3] = {0u, 0u, 0u};                                               // int32 arithmetic wraps in the reference binary
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const uint32_t v = p[i][j][k];
+                            if (i != 1) sum[0] += (uint32_t)((i - 1) * stamp_m(j, k)) * v;
+                            if (j != 1) sum[1] += (uint32_t)((j - 1) * stamp_m(i, k)) * v;
+                            if (k != 1) sum[2] += (uint32_t)((k - 1) * stamp_m(i, j)) * v;
+                        }
+                const int32_t weight = 812 * 0x100;
+                int16_t q16[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int32_t sv = (int32_t)sum[c];
+                    const int32_t q = sv < 0 ? (sv - weight / 2) / weight : (sv + weight / 2) / weight;   // divRoundClosest, image_util.h:34-38
+                    q16[c] = (int16_t)q;
+                    ovf |= (int32_t)q16[c] != q;
+                    a[c] = (float)q16[c];
+                }
+                o.x = q16[0]; o.y = q16[1]; o.z = q16[2];
+                o.w = (int16_t)((int32_t)(0x7FFFFFFFu - tr) / 0x10000);
+            }
+            field[idx] = o;
+            if (transl_cropped) transl_cropped[idx] = tr;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const uint32_t b = __float_as_uint(a[c]) & 0x7FFFFFFFu;
+                m[c] = b > m[c] ? b : m[c];
+                const uint32_t cc = ~(b - 1u);
+                m[4] = cc > m[4] ? cc : m[4];
+            }
+            const uint32_t q2 = __float_as_uint(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]) & 0x7FFFFFFFu;
+            m[3] = q2 > m[3] ? q2 : m[3];
+        }
+        if (t + 1 < nplanes) lstore((t + 1) & 1u);
+        tr_raw = tr_next;
+        __syncthreads();
+    }
+    if (ovf) atomicOr(&err->diff_overflow, 1u);
+    // workgroup reduction of the field scan -> five words per workgroup
+    __shared__ uint32_t s_m[kThreads / 64][5];
+#pragma unroll
+    for (int d = 0; d < 5; ++d) {
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t tt = (uint32_t)__shfl_xor((int)m[d], o); m[d] = tt > m[d] ? tt : m[d]; }
+        if ((tid & 63u) == 0) s_m[tid >> 6][d] = m[d];
+    }
+    __syncthreads();
+    if (tid < 5 && absmax_partial) {
+        uint32_t v = s_m[0][tid];
+        for (int w = 1; w < kThreads / 64; ++w) v = s_m[w][tid] > v ? s_m[w][tid] : v;
+        const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        absmax_partial[wg * 5 + tid] = v;
+    }
+}
+
+// folds the workgroups' five words: a few workgroups, one atomic per word each (out[] zeroed by the caller)
+__global__ __launch_bounds__(256) void k_absmax_reduce(const uint32_t *partial, size_t nwg, uint32_t *out /* [5] */)
+{
+    __shared__ uint32_t s_m[4][5];
+    uint32_t m[5] = {0u, 0u, 0u, 0u, 0u};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwg; i += (size_t)gridDim.x * blockDim.x)
+#pragma unroll
+        for (int d = 0; d < 5; ++d) { const uint32_t v = partial[i * 5 + d]; m[d] = v > m[d] ? v : m[d]; }
+#pragma unroll
+    for (int d = 0; d < 5; ++d) {
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)m[d], o); m[d] = t > m[d] ? t : m[d]; }
+        if ((threadIdx.x & 63u) == 0) s_m[threadIdx.x >> 6][d] = m[d];
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        uint32_t v = s_m[0][threadIdx.x];
+        for (int w = 1; w < 4; ++w) v = s_m[w][threadIdx.x] > v ? s_m[w][threadIdx.x] : v;
+        atomicMax(&out[threadIdx.x], v);
     }
 }
 

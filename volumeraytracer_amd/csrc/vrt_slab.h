@@ -99,17 +99,60 @@ __device__ __forceinline__ uint32_t mad_hi16(uint32_t a, uint32_t b, uint32_t c)
 // region around it made the compiler carry the divergence into the march that follows (lane 0 then
 // marched alone and staged only its own share of the brick) -- wave-level code must not sit behind a
 // divergent branch.
+// (the address is wave-uniform: it goes in as a scalar base beside a zero vector offset, so no counter or queue pointer
+// occupies a register pair per lane -- the 80-register kernels were spilling one)
 __device__ __forceinline__ uint32_t lane0_atomic_add(uint32_t *ptr, uint32_t v)
 {
     uint32_t old;
     unsigned long long saved;
     asm volatile("s_mov_b64 %1, exec\n\t"
                  "s_mov_b64 exec, 1\n\t"
-                 "global_atomic_add %0, %2, %3, off sc0\n\t"
+                 "global_atomic_add %0, %2, %3, %4 sc0\n\t"
                  "s_waitcnt vmcnt(0)\n\t"
                  "s_mov_b64 exec, %1"
-                 : "=&v"(old), "=&s"(saved) : "v"(ptr), "v"(v) : "memory");
+                 : "=&v"(old), "=&s"(saved) : "v"(0u), "v"(v), "s"(ptr) : "memory");
     return __builtin_amdgcn_readfirstlane(old);
+}
+// exchange by lane 0: returns the old word and leaves `v` (one atomic, so that taking a queue word and emptying it cannot
+// be separated by another wavefront's read)
+__device__ __forceinline__ uint32_t lane0_atomic_swap(uint32_t *ptr, uint32_t v)
+{
+    uint32_t old;
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %1, exec\n\t"
+                 "s_mov_b64 exec, 1\n\t"
+                 "global_atomic_swap %0, %2, %3, %4 sc0\n\t"
+                 "s_waitcnt vmcnt(0)\n\t"
+                 "s_mov_b64 exec, %1"
+                 : "=&v"(old), "=&s"(saved) : "v"(0u), "v"(v), "s"(ptr) : "memory");
+    return __builtin_amdgcn_readfirstlane(old);
+}
+// Scheduler words of the persistent schedules: head (items drawn), groups finished, error, tail (items appended).  They sit
+// kCtrStride words apart (development: 1 = one 128-byte line, as in round 2; 32 = a line each).
+#ifndef VRT_CTR_STRIDE
+#define VRT_CTR_STRIDE 1
+#endif
+constexpr uint32_t kCtrStride = VRT_CTR_STRIDE;
+constexpr uint32_t kCtrHead = 0, kCtrDone = 1 * kCtrStride, kCtrErr = 2 * kCtrStride, kCtrTail = 3 * kCtrStride, kCtrWords = 3 * kCtrStride + 1;
+// A wavefront of the time-sliced schedule that gives up waiting: the device error word counts it, the "groups finished" word
+// is pushed past any group count so that every other waiter leaves at its next look (the waiters poll that word anyway: a
+// second polled word on the counters' line was measured in round 3 -- idle wavefronts at the end of a launch saturate the
+// line and the whole schedule ran 17 - 34 % slower), and the host word (pinned, written through to system scope) tells the
+// caller that rays were left unfinished.
+__device__ __forceinline__ void raise_sched_error(uint32_t *ctr, uint32_t *host_err)
+{
+    (void)lane0_atomic_add(ctr + kCtrErr, 1u);
+    (void)lane0_atomic_add(ctr + kCtrDone, 0x40000000u);
+    if (host_err) {
+        unsigned long long saved;
+        uint32_t one = 1u;
+        asm volatile("s_mov_b64 %0, exec\n\t"
+                     "s_mov_b64 exec, 1\n\t"
+                     "global_store_dword %1, %2, %3 sc0 sc1\n\t"
+                     "s_waitcnt vmcnt(0)\n\t"
+                     "s_mov_b64 exec, %0"
+                     : "=&s"(saved) : "v"(0u), "v"(one), "s"(host_err) : "memory");
+    }
 }
 __device__ __forceinline__ uint64_t lane_mask(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 // compare-and-swap by lane 0 (same EXEC narrowing): *ptr = (*ptr == expect) ? value : *ptr; returns the old word
@@ -120,10 +163,10 @@ __device__ __forceinline__ uint32_t lane0_atomic_cas(uint32_t *ptr, uint32_t exp
     const unsigned long long pair = ((unsigned long long)expect << 32) | value;      // {data, compare} in consecutive registers
     asm volatile("s_mov_b64 %1, exec\n\t"
                  "s_mov_b64 exec, 1\n\t"
-                 "global_atomic_cmpswap %0, %2, %3, off sc0\n\t"
+                 "global_atomic_cmpswap %0, %2, %3, %4 sc0\n\t"
                  "s_waitcnt vmcnt(0)\n\t"
                  "s_mov_b64 exec, %1"
-                 : "=&v"(old), "=&s"(saved) : "v"(ptr), "v"(pair) : "memory");
+                 : "=&v"(old), "=&s"(saved) : "v"(0u), "v"(pair), "s"(ptr) : "memory");
     return __builtin_amdgcn_readfirstlane(old);
 }
 
@@ -447,8 +490,8 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
     // `rem_w` and zeroes `it`, so "it > 0 and inside the field" is the only liveness predicate.
     Ray r;
     uint32_t it, rem_w, light;                          // light: brightness, ABSORB only (.cu:332)
-    uint32_t slot, ray;
-    bool have;
+    // (the ray's index is not kept across the march: it is looked up again from the group's first slot when the ray is
+    // stored -- three registers fewer live through the loops, which the 80-register instantiations were spilling)
 #if defined(VRT_SLAB_TIMELINE) || defined(VRT_SLAB_PHASES)   // development builds (tools/timeline.py, tools/phases.py)
     uint32_t tl_lds = 0, tl_dir = 0, tl_rounds = 0;
 #define VRT_TL(x) (x)
@@ -694,18 +737,18 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
             // steps in a row: the corners stay in registers and only lanes that entered a new cell gather again
             // (a quarter of the lanes per step).  At 4 waves/SIMD (128 registers) the eight CONVERTED corners
             // (32 registers) stay live for either field type: config 3 (fp32 field) 8.15 -> 7.31 ms -- its global-gather
-            // rounds were 8 % of the steps but 16 % of a wavefront's life.  With fewer registers (6 waves/SIMD, 80)
-            // only an int16 field's RAW corners (16 registers) fit (-6 % on config 5 in round 1); fp32 corners spill
-            // there (+27 % on config 3, and still at 5 waves/SIMD with 96 registers), so that case gathers every step.
+            // rounds were 8 % of the steps but 16 % of a wavefront's life.  With 80 registers (6 waves/SIMD) they do not
+            // fit (fp32 corners spilled: +27 % on config 3, and still at 5 waves/SIMD), so those kernels gather every step.
+            // (Rounds 1 and 2 kept an int16 field's RAW corners, 16 registers, in the 80-register kernels: it cost 20 - 44
+            // bytes of scratch per lane and, measured in round 3 on 512^3 int16 with 2048^2 rays, was 0.9 % slower than
+            // gathering every step -- 21.97 vs 21.78 ms; 96 registers at 5 waves/SIMD: 22.46 -- so it is gone.)
 #ifdef VRT_NO_KEEP_F32
             constexpr bool kKeepF32 = OCC < 0;                  // (development: A/B)
 #else
             constexpr bool kKeepF32 = OCC <= 4;
 #endif
-            constexpr bool kKeepCorners = !kKeepF32 && sizeof(FieldT) == 2;
-            vox kept[kKeepCorners ? 8 : 1];
             f4 keptf[kKeepF32 ? 8 : 1];
-            uint32_t have_xy = 0xFFFFFFFFu, have_z = 0xFFFFFFFFu;   // cell of the corners in kept[]: (x | y << 16, z); none yet
+            uint32_t have_xy = 0xFFFFFFFFu, have_z = 0xFFFFFFFFu;   // cell of the corners in keptf[]: (x | y << 16, z); none yet
             const int direct_steps = SLICED ? (int)(budget < (uint32_t)kSlabDirectSteps ? budget : (uint32_t)kSlabDirectSteps) : kSlabDirectSteps;
             for (int k = 0; k < direct_steps; ++k) {
                 const bool alive = it > 0 && in_field(r, bx1, by1, bz1);
@@ -728,17 +771,7 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                             if (march_step(r, keptf, invx, invy, invz, win)) { rem_w = it; it = 0; } else --it;
                         } else {
                             f4 c[8];
-                            if constexpr (kKeepCorners) {
-                                if (xy != have_xy || z != have_z) {
-                                    gather_global_raw<FieldT>(f, r, p.By, p.Bz, kept);
-                                    have_xy = xy;
-                                    have_z = z;
-                                }
-#pragma unroll
-                                for (int q = 0; q < 8; ++q) cvt_vox(kept[q], c[q]);
-                            } else {
-                                gather_global<FieldT>(f, r, p.By, p.Bz, c);
-                            }
+                            gather_global<FieldT>(f, r, p.By, p.Bz, c);
                             if (march_step(r, c, invx, invy, invz, win)) { rem_w = it; it = 0; } else --it;
                         }
                     }
@@ -907,37 +940,50 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
     };
 #endif
     auto begin_group = [&](uint32_t first_slot) {        // fill_struct (.cu:468-487): fresh rays from the caller's arrays
-        slot = first_slot + lane;
-        have = slot < p.nrays;
-        ray = have ? (p.order ? p.order[slot] : slot) : 0u;
+        const uint32_t slot = first_slot + lane;
+        const bool have = slot < p.nrays;
+        const uint32_t ray = have ? (p.order ? p.order[slot] : slot) : 0u;
         r.px = r.py = r.pz = 0; r.dx = r.dy = r.dz = 1.0f;
         if (have) load_ray<DirT>(p, ray, r);
         it = have ? p.iterations - 1 : 0u;
         rem_w = 0xFFFFFFFFu;
         light = 0xFFFFFFFFu;
     };
+    auto end_group = [&](uint32_t first_slot) {          // read_struct (.cu:490-516, 952-956): results to the ray's own index
+        const uint32_t slot = first_slot + lane;
+        if (slot < p.nrays) store_ray<DirT>(p, p.order ? p.order[slot] : slot, r, rem_w != 0xFFFFFFFFu ? rem_w : it, light);
+    };
 
     // wave 0 of block 0 notes the shader clock (s_memtime) against the 100 MHz wall clock (s_memrealtime) around its
     // whole life: the clock the kernel really ran at (bench.py prices the VALU-issue roofline with it)
+    // (the begin stamps are stored at once: kept in registers until the end they were four VGPRs live across the whole
+    // kernel, which the 80-register instantiations spilled to scratch)
     const bool stamps = p.clock_out != nullptr && blockIdx.x == 0 && threadIdx.x < 64;
-    unsigned long long ck_t0 = 0, ck_r0 = 0;
-    if (stamps) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ck_t0), "=s"(ck_r0) :: "memory");
+    if (stamps) {
+        unsigned long long t0, r0;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0) :: "memory");
+        if (lane == 0) { p.clock_out[0] = t0; p.clock_out[1] = r0; }
+    }
     auto clock_stamp_end = [&]() {
         if (stamps) {
             unsigned long long t1, r1;
             asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) :: "memory");
-            if (lane == 0) { p.clock_out[0] = ck_t0; p.clock_out[1] = ck_r0; p.clock_out[2] = t1; p.clock_out[3] = r1; }
+            if (lane == 0) { p.clock_out[2] = t1; p.clock_out[3] = r1; }
         }
     };
 
     if constexpr (!PERSIST) {
         // one wavefront per group of 64 slots; the hardware dispatcher hands out groups in launch order
-        begin_group(launch_slot(p) & ~63u);
+        const uint32_t first = sgpr(launch_slot(p) & ~63u);
+        const uint32_t slot = first + lane;
+        const bool have = slot < p.nrays;
+        begin_group(first);
 #ifdef VRT_SLAB_TIMELINE
         if (p.stats && lane == 0) p.stats[64 + 4 * (size_t)(slot >> 6)] = wall_clock64();
 #endif
         march();
-        if (have) store_ray<DirT>(p, ray, r, rem_w != 0xFFFFFFFFu ? rem_w : it, light);
+        end_group(first);
+        (void)have;
 #ifdef VRT_SLAB_PHASES
         tl_lds_total += tl_lds; tl_dir_total += tl_dir; tl_rounds_total += tl_rounds;
         ph_flush();
@@ -987,7 +1033,7 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
             slice = sgpr(slice);
         }
         for (;;) {
-            const uint32_t item = lane0_atomic_add(ctr, 1u);
+            const uint32_t item = lane0_atomic_add(ctr + kCtrHead, 1u);
             VRT_SL(++sl_tickets);
             uint32_t g;
             if (item < ngroups) {
@@ -995,23 +1041,32 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                 begin_group(g * 64u);
             } else {
                 uint32_t *qe = p.slice_flags + ((item - ngroups) & (p.ticket_limit - 1u));     // ring of ticket_limit = 2^k words
-                uint32_t q = lane0_atomic_add(qe, 0u);
+                // take the word and empty it for its next lap in ONE exchange: with a read followed by a second atomic, the
+                // holder of the ticket one lap later could read the same word in between and resume the group a second time
+#ifdef VRT_OLD_CONSUMER                                             // (development: A/B of the round-2 read-then-add consumer)
+#define VRT_TAKE(qe) lane0_atomic_add(qe, 0u)
+#else
+#define VRT_TAKE(qe) lane0_atomic_swap(qe, 0u)
+#endif
+                uint32_t q = VRT_TAKE(qe);
                 VRT_SL(sl_waits += q == 0u ? 1u : 0u);
                 bool finished = false;
                 for (uint32_t spin = 0; q == 0u; ++spin) {
                     // nothing appended yet: either every group has finished (leave) or a running group will append
-                    if ((spin & 15u) == 0u && lane0_atomic_add(ctr + 1, 0u) >= ngroups) { finished = true; break; }
-                    if (spin >= (1u << 22)) { (void)lane0_atomic_add(ctr + 2, 1u); finished = true; break; }   // never hang
+                    if ((spin & 15u) == 0u) {
+                        if (lane0_atomic_add(ctr + kCtrDone, 0u) >= ngroups) { finished = true; break; }   // (or somebody gave up: raise_sched_error)
+                    }
+                    if (spin >= p.spin_limit) { raise_sched_error(ctr, p.sched_err); finished = true; break; }   // never hang
                     __builtin_amdgcn_s_sleep(127);
-                    q = lane0_atomic_add(qe, 0u);
+                    q = VRT_TAKE(qe);
                     VRT_SL(++sl_polls);
                 }
                 if (finished) break;
-                (void)lane0_atomic_add(qe, 0u - q);                          // empty the word for its next lap
+#ifdef VRT_OLD_CONSUMER
+                (void)lane0_atomic_add(qe, 0u - q);
+#endif
+#undef VRT_TAKE
                 g = q - 1u;
-                slot = g * 64u + lane;
-                have = slot < p.nrays;
-                ray = have ? (p.order ? p.order[slot] : slot) : 0u;
                 const u32x4 *park = (const u32x4 *)p.park + (size_t)g * 128u + lane;      // [group][2][64 lanes] x 16 B
                 u32x4 a, b;
                 load_sc1_2xb128(park, park + 64, a, b);
@@ -1030,16 +1085,16 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                 store_sc1_b128(park, a);
                 store_sc1_b128(park + 64, b);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the state is out before the group is queued
-                const uint32_t at = lane0_atomic_add(ctr + 3, 1u);
+                const uint32_t at = lane0_atomic_add(ctr + kCtrTail, 1u);
                 uint32_t *qw = p.slice_flags + (at & (p.ticket_limit - 1u));
                 uint32_t spin = 0;
                 while (lane0_atomic_cas(qw, 0u, g + 1u) != 0u) {             // 0 -> g + 1; occupied only in the race described above
-                    if (++spin >= (1u << 22)) { (void)lane0_atomic_add(ctr + 2, 1u); break; }   // never hang
+                    if (++spin >= p.spin_limit) { raise_sched_error(ctr, p.sched_err); break; }   // never hang
                     __builtin_amdgcn_s_sleep(16);
                 }
             } else {
-                if (have) store_ray<DirT>(p, ray, r, rem_w != 0xFFFFFFFFu ? rem_w : it, light);
-                (void)lane0_atomic_add(ctr + 1, 1u);
+                end_group(g * 64u);
+                (void)lane0_atomic_add(ctr + kCtrDone, 1u);
             }
 #ifdef VRT_SLAB_PHASES
             tl_lds_total += tl_lds; tl_dir_total += tl_dir; tl_rounds_total += tl_rounds;
@@ -1058,13 +1113,17 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
         for (;;) {
             const uint32_t fr = lane0_atomic_add(p.group_counter, 1u);
             if (fr >= ngroups) break;
-            begin_group((p.wave_order ? sgpr(p.wave_order[fr]) : fr) * 64u);
+            const uint32_t first = (p.wave_order ? sgpr(p.wave_order[fr]) : fr) * 64u;
+            const uint32_t slot = first + lane;
+            const bool have = slot < p.nrays;
+            begin_group(first);
 #ifdef VRT_SLAB_TIMELINE
             if (p.stats && lane == 0) p.stats[64 + 4 * (size_t)(slot >> 6)] = wall_clock64();
             tl_lds = tl_dir = tl_rounds = 0;
 #endif
             march();
-            if (have) store_ray<DirT>(p, ray, r, rem_w != 0xFFFFFFFFu ? rem_w : it, light);
+            end_group(first);
+            (void)have; (void)slot;
 #ifdef VRT_SLAB_PHASES
             tl_lds_total += tl_lds; tl_dir_total += tl_dir; tl_rounds_total += tl_rounds;
             tl_lds = tl_dir = tl_rounds = 0;
@@ -1112,8 +1171,6 @@ inline SlabGeometry slab_geometry(uint32_t want, uint32_t nrays, uint32_t Bx, ui
 #else
     const bool all = false;
 #endif
-    if (want <= 4096) return {4096, 8, all};
-    if (want <= 5120) return {5120, 7, all};
     if (want <= 6144) return {6144, 6, true};
     if (want <= 8192) return {8192, 5, all};
     if (want <= 10240) return {10240, 4, true};
@@ -1156,8 +1213,6 @@ hipError_t launch_slab(const MarchParams &p, SlabGeometry g, int num_cu, hipStre
         return launch_slab_bytes<FieldT, DirT, 10240, 4, true, true>(p, num_cu, s);
     }
     switch (g.seg_bytes) {
-    case 4096:  return launch_slab_bytes<FieldT, DirT, 4096, 8, false, kAll>(p, num_cu, s);
-    case 5120:  return launch_slab_bytes<FieldT, DirT, 5120, 7, false, kAll>(p, num_cu, s);
     case 6144:  return launch_slab_bytes<FieldT, DirT, 6144, 6, false, true>(p, num_cu, s);
     case 8192:  return launch_slab_bytes<FieldT, DirT, 8192, 5, false, kAll>(p, num_cu, s);
     case 10240: return launch_slab_bytes<FieldT, DirT, 10240, 4, false, true>(p, num_cu, s);

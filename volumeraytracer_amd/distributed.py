@@ -127,6 +127,25 @@ class RecordGather:
         return [self.recv[self.last][r][:RECORD_WORDS * self.counts[r]] for r in range(self.world)]
 
 
+def sample_gathered(counts, nsample):
+    """Evenly strided sample of the whole job's rays for the check of the gathered records (bench.py, N > 1): global ray
+    indices 0, s, 2s, ... over sum(counts), split by owning rank.  Returns [(rank, local index array)] for every rank
+    (possibly empty arrays); every rank with at least one ray gets at least one sample."""
+    counts = [int(c) for c in counts]
+    total = sum(counts)
+    if total == 0 or nsample <= 0:
+        return [(r, np.zeros(0, np.int64)) for r in range(len(counts))]
+    g = np.unique(np.linspace(0, total - 1, min(int(nsample), total)).astype(np.int64))
+    out, base = [], 0
+    for r, c in enumerate(counts):
+        loc = g[(g >= base) & (g < base + c)] - base
+        if loc.size == 0 and c > 0:
+            loc = np.array([c // 2], np.int64)
+        out.append((r, loc))
+        base += c
+    return out
+
+
 def assemble(records, counts):
     """dst side: concatenate per-rank records back into whole-job arrays in global ray order
     (rank r's rays precede rank r+1's).  Returns dict of numpy arrays (bit patterns, uint32)."""
