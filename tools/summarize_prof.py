@@ -13,7 +13,7 @@ import os
 import sys
 
 KEEP = ("k_march", "k_tile_keys", "k_interleave", "radix", "onesweep", "rocprim", "k_wave_work", "k_ray_bounds", "k_scene_build",
-        "k_ray_prologue", "k_field_absmax", "k_absmax_reduce")
+        "k_ray_prologue", "k_field_absmax", "k_absmax_reduce", "k_wave_sort")
 
 
 def short(name):

@@ -128,9 +128,9 @@ __device__ __forceinline__ uint32_t lane0_atomic_swap(uint32_t *ptr, uint32_t v)
     return __builtin_amdgcn_readfirstlane(old);
 }
 // Scheduler words of the persistent schedules: head (items drawn), groups finished, error, tail (items appended).  They sit
-// kCtrStride words apart (development: 1 = one 128-byte line, as in round 2; 32 = a line each).
+// kCtrStride words apart (32 words = a 128-byte line each; round 2 had them on one line: the two layouts measure the same within 1 %, see DESIGN).
 #ifndef VRT_CTR_STRIDE
-#define VRT_CTR_STRIDE 1
+#define VRT_CTR_STRIDE 32
 #endif
 constexpr uint32_t kCtrStride = VRT_CTR_STRIDE;
 constexpr uint32_t kCtrHead = 0, kCtrDone = 1 * kCtrStride, kCtrErr = 2 * kCtrStride, kCtrTail = 3 * kCtrStride, kCtrWords = 3 * kCtrStride + 1;
@@ -747,6 +747,12 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
 #else
             constexpr bool kKeepF32 = OCC <= 4;
 #endif
+            // Tried in round 3 and dropped (MI355X, kernel ms, config 5 / config 3; base 13.3 / 7.0): (a) FACE SHIFT -- a lane that
+            // moves one cell forward along the wavefront's dominant axis keeps the far face as the new near face and gathers only
+            // four corners (half the cache lines; six compile-time copies of this loop, one per axis and sign): 13.9 - 14.3 /
+            // 7.29, global-gather step 2 190 -> 2 510 wall cycles -- fewer lines do not help; (b) the same with the face BEYOND
+            // the cell prefetched into 16 (fp32) / 8 (int16 raw) more registers, so that a forward move needs no memory round
+            // trip at all: 16.6 / 7.9, step 4 420 cycles, and 172 - 200 B of scratch in the fp32 kernels.
             f4 keptf[kKeepF32 ? 8 : 1];
             uint32_t have_xy = 0xFFFFFFFFu, have_z = 0xFFFFFFFFu;   // cell of the corners in keptf[]: (x | y << 16, z); none yet
             const int direct_steps = SLICED ? (int)(budget < (uint32_t)kSlabDirectSteps ? budget : (uint32_t)kSlabDirectSteps) : kSlabDirectSteps;

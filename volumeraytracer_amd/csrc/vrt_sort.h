@@ -200,6 +200,54 @@ __global__ __launch_bounds__(256) void k_wave_work(const typename FieldTraits<Fi
     if (threadIdx.x == 0) atomicAdd(&rb->work_sum, (unsigned long long)s_sum);
 }
 
+// Launch order of the wavefronts from their work keys (kCoarseMaxLoops - estimate, 12 bits): ONE workgroup sorts them by
+// counting in LDS -- histogram with LDS atomics, scan of the 2049 bins, scatter.  (Rounds 1 and 2 called rocPRIM's radix sort
+// here: six to eight small dependent launches, about 40 us plus their gaps, for 16 384 keys.)  Ties come out in arbitrary
+// order: the launch order is a scheduling hint, results never depend on it.
+constexpr int kWaveSortThreads = 1024;
+__global__ __launch_bounds__(kWaveSortThreads) void k_wave_sort(const uint32_t *__restrict__ wkeys, uint32_t nw, uint32_t *__restrict__ order_out)
+{
+    constexpr int kBins = kCoarseMaxLoops + 1;
+    constexpr int kPer = (kBins + kWaveSortThreads - 1) / kWaveSortThreads;     // bins per thread in the scan (3)
+    __shared__ uint32_t cnt[kBins];
+    __shared__ uint32_t wsum[kWaveSortThreads / 64];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t b = tid; b < (uint32_t)kBins; b += kWaveSortThreads) cnt[b] = 0u;
+    __syncthreads();
+    for (uint32_t i = tid; i < nw; i += kWaveSortThreads) {
+        const uint32_t k = wkeys[i];
+        atomicAdd(&cnt[k < (uint32_t)kBins ? k : (uint32_t)kBins - 1u], 1u);
+    }
+    __syncthreads();
+    // exclusive scan: thread t owns bins [t * kPer, t * kPer + kPer)
+    uint32_t mine[kPer], tot = 0;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const uint32_t b = tid * kPer + j;
+        mine[j] = b < (uint32_t)kBins ? cnt[b] : 0u;
+        tot += mine[j];
+    }
+    uint32_t incl = tot;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o); if ((tid & 63u) >= (uint32_t)o) incl += t; }
+    if ((tid & 63u) == 63u) wsum[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < (tid >> 6); ++w) base += wsum[w];
+    uint32_t run = base + incl - tot;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const uint32_t b = tid * kPer + j;
+        if (b < (uint32_t)kBins) cnt[b] = run;
+        run += mine[j];
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < nw; i += kWaveSortThreads) {
+        const uint32_t k = wkeys[i];
+        order_out[atomicAdd(&cnt[k < (uint32_t)kBins ? k : (uint32_t)kBins - 1u], 1u)] = i;
+    }
+}
+
 // grow-only device buffer interface expected from the caller (see DevBuf in vrt_engine.hip)
 template <typename Buf>
 hipError_t build_tile_order(const uint32_t *d_pos, const void *d_dir, int dir_is_i16, uint32_t n,
@@ -247,14 +295,8 @@ hipError_t build_tile_order(const uint32_t *d_pos, const void *d_dir, int dir_is
         else              { if (dir_is_i16) VRT_WW(float, int16_t, vf);   else VRT_WW(float, float, vf); }
 #undef VRT_WW
         if ((e = hipGetLastError()) != hipSuccess) return e;
-        size_t wtmp = 0;
-        constexpr int kWaveKeyBits = 12;                   // keys are in [0, kCoarseMaxLoops = 2048]: two radix passes instead of four
-        static_assert(kCoarseMaxLoops < (1 << kWaveKeyBits), "wavefront sort key width");
-        e = rocprim::radix_sort_pairs(nullptr, wtmp, (const uint32_t *)wk, wk + nw, (const uint32_t *)wv, wv + nw, nw, 0, kWaveKeyBits, s);
-        if (e != hipSuccess) return e;
-        if (wtmp > tmp_bytes && (e = tmp.reserve(wtmp)) != hipSuccess) return e;
-        e = rocprim::radix_sort_pairs(tmp.p, wtmp, (const uint32_t *)wk, wk + nw, (const uint32_t *)wv, wv + nw, nw, 0, kWaveKeyBits, s);
-        if (e != hipSuccess) return e;
+        k_wave_sort<<<1, kWaveSortThreads, 0, s>>>(wk, nw, wv + nw);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
         *wave_order_out = wv + nw;
     }
     return hipSuccess;
