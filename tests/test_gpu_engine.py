@@ -390,3 +390,36 @@ def test_scheduler_give_up_is_reported(monkeypatch):
         o, _, keep = _device_call(eng, torch, dev, sp, sd, options=capi.default_options(kernel=capi.KERNEL_DIRECT))
         torch.cuda.synchronize()
         assert eng.last_schedule() == 0
+
+
+@pytest.mark.parametrize("fdt,ddt", [(np.float32, np.float32), (np.int16, np.int16)])
+def test_tile_order_kernels_on_uneven_ray_sets(monkeypatch, fdt, ddt):
+    """The hand-written tile order (count per tile, scan, scatter, in-tile ranks: vrt_sort.h) must yield a permutation
+    whatever the ray set looks like -- every ray marched exactly once, results at the rays' own indices: random rays in
+    all six dominant directions and several depth bins (tiles holding rays of several kinds), 30 000 rays crowded
+    into one spot plus a few outliers that stretch the tile grid (segments far longer than the 512 the in-tile pass
+    orders: the copy-through branch), many identical rays, and a set just above the sort threshold.  Same bits as the
+    oracle, and as the radix-sort order of rounds 1 and 2."""
+    N = 56
+    bounds, dx, dy, dz, tc = W.seam_field(N, fdt, seed=31, opaque_radius=4.0)
+    field = oracle.port.interleave(dx, dy, dz, tc)
+    rng = np.random.RandomState(123)
+    sp_r, sd_r = W.random_rays(N, 20000, ddt, seed=7, vol_seed=31)
+    # crowded: starts within a quarter voxel of one point, directions in a narrow cone; plus 5 far-away outliers
+    c = np.array([20.3, 31.7, 25.1])
+    pv = np.concatenate([c + (rng.rand(30000, 3) - 0.5) * 0.25, 2.0 + rng.rand(5, 3) * (N - 6.0)])
+    dd = np.array([1.0, 0.05, -0.02]) + rng.randn(30005, 3) * 0.01
+    dd /= np.linalg.norm(dd, axis=1)[:, None]
+    sp_c = np.round((pv - 1.0) * 65536).astype(np.uint32).reshape(-1)
+    sd_c = dd.astype(np.float32).reshape(-1) if ddt == np.float32 else np.round(dd * 256).astype(np.int16).reshape(-1)
+    sp_i, sd_i = np.tile(sp_r[:3], 5000), np.tile(sd_r[:3], 5000)              # 5000 identical rays
+    sets = {"random": (sp_r, sd_r), "crowded": (sp_c, sd_c), "identical": (sp_i, sd_i), "threshold": (sp_r[:3 * 4097], sd_r[:3 * 4097])}
+    with capi.Engine.from_host(bounds, [dx, dy, dz], tc) as eng:
+        for name, (sp, sd) in sets.items():
+            want = oracle.port.trace(field, bounds, sp, sd, [1, 1, 1], 100000)
+            for order in ("tiles", "radix"):
+                monkeypatch.setenv("VRT_RAY_ORDER", order)
+                for kern in (capi.KERNEL_SLAB, capi.KERNEL_DIRECT):
+                    got = eng.trace(sp, sd, [1, 1, 1], 100000, options=capi.default_options(kernel=kern, sort_rays=1))
+                    for k in KEYS:
+                        assert _same(got[k], want[k]), (name, order, kern, k)

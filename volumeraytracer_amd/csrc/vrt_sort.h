@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 #include "vrt_march.h"
 
 namespace vrt {
@@ -70,12 +72,9 @@ __global__ __launch_bounds__(256) void k_ray_bounds(const uint32_t *pos, uint32_
 // 10^6 rays).  The optional work bucket orders wavefronts longest-first (LPT) from the straight-line
 // distance to the field boundary; off by default (measured: -2 % on config 4, +12 % on config 3).
 template <typename DirT>
-__global__ __launch_bounds__(256) void k_tile_keys(const uint32_t *pos, const DirT *dir, uint32_t n,
-                                                   const RayBounds *rb, uint32_t Bx, uint32_t By, uint32_t Bz,
-                                                   int lpt, uint32_t *keys, uint32_t *vals)
+__device__ __forceinline__ uint32_t tile_key(const uint32_t *pos, const DirT *dir, uint32_t i, uint32_t n, const RayBounds *rb,
+                                             uint32_t Bx, uint32_t By, uint32_t Bz, int lpt)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
     const uint32_t p[3] = {pos[3 * (size_t)i], pos[3 * (size_t)i + 1], pos[3 * (size_t)i + 2]};
     const float dx = (float)dir[3 * (size_t)i], dy = (float)dir[3 * (size_t)i + 1], dz = (float)dir[3 * (size_t)i + 2];
     const float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
@@ -121,8 +120,137 @@ __global__ __launch_bounds__(256) void k_tile_keys(const uint32_t *pos, const Di
         const int b = (int)(len * 6.0f / fmaxf(fmaxf(hi3[0], hi3[1]), hi3[2]));
         bucket = (uint32_t)(b < 0 ? 0 : (b > 7 ? 7 : b));
     }
-    keys[i] = ((7u - bucket) << 29) | (dom << 26) | (wb << 22) | (tu << 14) | (tv << 6) | (row << 3) | col;
+    return ((7u - bucket) << 29) | (dom << 26) | (wb << 22) | (tu << 14) | (tv << 6) | (row << 3) | col;
+}
+
+template <typename DirT>
+__global__ __launch_bounds__(256) void k_tile_keys(const uint32_t *pos, const DirT *dir, uint32_t n,
+                                                   const RayBounds *rb, uint32_t Bx, uint32_t By, uint32_t Bz,
+                                                   int lpt, uint32_t *keys, uint32_t *vals)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = tile_key<DirT>(pos, dir, i, n, rb, Bx, By, Bz, lpt);
     vals[i] = i;
+}
+
+// ---- the tile order without a general sort (round 3) -------------------------------------------------------------
+// The key above is (dom | depth bin | tile u | tile v | row | column): what the march needs is that the rays of one tile
+// end up in 64 consecutive slots, tiles in serpentine order, and -- a refinement -- row-major order inside a tile.  A
+// radix sort of the whole key (rocPRIM, rounds 1 and 2: 21 dependent launches, about 150 us at 10^6 rays, the one library
+// call on the timed path) does far more than that.  Here: count the rays per tile (tile u, tile v: 65 536 bins, global
+// atomics), scan the bins in one workgroup, scatter the rays to their tile's segment, and let one wavefront per tile put
+// its segment -- about 64 rays -- in order by counting ranks out of LDS.  Dominant direction and depth bin become the leading
+// bits of the in-tile key, so that a tile holding rays of several kinds keeps them in separate runs.  Four launches.
+constexpr uint32_t kTileBins = 65536u;
+constexpr uint32_t kTileSortMax = 512u;                 // largest segment ordered in place; longer ones (the tile grid is sized
+                                                        // for 64 rays per tile: only grossly uneven ray sets) stay as scattered
+__device__ __forceinline__ uint32_t tile_bin(uint32_t key) { return (key >> 6) & 0xFFFFu; }
+__device__ __forceinline__ uint32_t tile_sub(uint32_t key) { return ((key >> 22) & 0x7Fu) << 6 | (key & 0x3Fu); }   // dom:3 | depth:4 | row:3 | col:3
+
+// Rays usually arrive in some raster order, so consecutive lanes of a wavefront fall into the same tile in runs (8 at a time
+// for a lattice): one atomic per RUN instead of one per lane -- same-address atomics of one instruction serialise, and with
+// one per ray the two atomic passes took 100 and 121 us at 10^6 rays, more than the radix sort they replace.  run_of() gives
+// every lane the first lane of its run of equal bins among consecutive lanes, its place in the run and the run's length.
+struct LaneRun { uint32_t first, place, length; };
+__device__ __forceinline__ LaneRun run_of(uint32_t bin, bool valid)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t prev = (uint32_t)__shfl_up((int)bin, 1);
+    const bool pvalid = __shfl_up((int)valid, 1) != 0;
+    const bool starts = lane == 0u || prev != bin || !pvalid || !valid;
+    const unsigned long long m = __ballot(starts);                        // bit l: lane l starts a run
+    const unsigned long long below = m & (~0ull >> (63u - lane));         // run starts at or below this lane (lane 0 always)
+    const uint32_t first = 63u - (uint32_t)__builtin_clzll(below);
+    const unsigned long long above = lane == 63u ? 0ull : (m >> (lane + 1u));
+    const uint32_t end = above ? lane + (uint32_t)__builtin_ctzll(above) : 63u;   // last lane of the run
+    return {first, lane - first, end - first + 1u};
+}
+
+template <typename DirT>
+__global__ __launch_bounds__(256) void k_tile_hist(const uint32_t *pos, const DirT *dir, uint32_t n, const RayBounds *rb, uint32_t Bx,
+                                                   uint32_t By, uint32_t Bz, uint32_t *keys, uint32_t *bins)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n;
+    uint32_t key = 0;
+    if (valid) { key = tile_key<DirT>(pos, dir, i, n, rb, Bx, By, Bz, 0); keys[i] = key; }
+    const LaneRun r = run_of(tile_bin(key), valid);
+    if (valid && r.place == 0u) atomicAdd(&bins[tile_bin(key)], r.length);
+}
+
+// exclusive scan of the 65 536 tile counts, in place, by one workgroup (64 bins per thread)
+__global__ __launch_bounds__(1024) void k_tile_scan(uint32_t *bins)
+{
+    constexpr uint32_t kPer = kTileBins / 1024u;
+    __shared__ uint32_t wsum[16];
+    const uint32_t tid = threadIdx.x;
+    uint32_t loc[kPer], tot = 0;
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    u4 *vb = (u4 *)(bins + tid * kPer);                   // 64 consecutive words per thread: 16-byte accesses
+#pragma unroll
+    for (uint32_t j = 0; j < kPer / 4u; ++j) {
+        const u4 v = vb[j];
+        loc[4 * j] = v.x; loc[4 * j + 1] = v.y; loc[4 * j + 2] = v.z; loc[4 * j + 3] = v.w;
+        tot += (v.x + v.y) + (v.z + v.w);
+    }
+    uint32_t incl = tot;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o); if ((tid & 63u) >= (uint32_t)o) incl += t; }
+    if ((tid & 63u) == 63u) wsum[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t run = incl - tot;
+    for (uint32_t w = 0; w < (tid >> 6); ++w) run += wsum[w];
+#pragma unroll
+    for (uint32_t j = 0; j < kPer / 4u; ++j) {
+        u4 v;
+        v.x = run; run += loc[4 * j];
+        v.y = run; run += loc[4 * j + 1];
+        v.z = run; run += loc[4 * j + 2];
+        v.w = run; run += loc[4 * j + 3];
+        vb[j] = v;
+    }
+}
+
+// every ray to its tile's segment; the bin's word ends up as the segment's END (the next bin's start)
+__global__ __launch_bounds__(256) void k_tile_scatter(const uint32_t *keys, uint32_t n, uint32_t *bins, uint32_t *sub_out, uint32_t *ray_out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n;
+    const uint32_t key = valid ? keys[i] : 0u;
+    const LaneRun r = run_of(tile_bin(key), valid);
+    uint32_t base = 0;
+    if (valid && r.place == 0u) base = atomicAdd(&bins[tile_bin(key)], r.length);       // one atomic per run of equal tiles
+    base = (uint32_t)__shfl((int)base, (int)r.first);
+    if (!valid) return;
+    const uint32_t at = base + r.place;
+    sub_out[at] = tile_sub(key);
+    ray_out[at] = i;
+}
+
+// one wavefront per tile: rank of every ray of the segment by (in-tile key, position in the segment) -- unique, so the
+// rank is the number of smaller ones -- counted against the segment's keys in LDS
+__global__ __launch_bounds__(256) void k_tile_order(const uint32_t *bins, const uint32_t *sub, const uint32_t *ray, uint32_t *order)
+{
+    __shared__ uint32_t s_key[4][kTileSortMax];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t bin = blockIdx.x * 4u + wave;
+    const uint32_t end = bins[bin], start = bin ? bins[bin - 1u] : 0u;
+    const uint32_t cnt = end - start;
+    if (cnt == 0u) return;
+    if (cnt > kTileSortMax) {                              // (wave-uniform) copy through
+        for (uint32_t e = lane; e < cnt; e += 64u) order[start + e] = ray[start + e];
+        return;
+    }
+    uint32_t *k = s_key[wave];
+    for (uint32_t e = lane; e < cnt; e += 64u) k[e] = (sub[start + e] << 9) | e;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t e = lane; e < cnt; e += 64u) {
+        const uint32_t mine = k[e];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < cnt; ++j) rank += k[j] < mine ? 1u : 0u;
+        order[start + rank] = ray[start + e];
+    }
 }
 
 // Longest-first launch order of whole wavefronts.  A launch of W wavefronts on S resident slots runs
@@ -270,17 +398,33 @@ hipError_t build_tile_order(const uint32_t *d_pos, const void *d_dir, int dir_is
     const unsigned rgrid = (unsigned)((n + 255) / 256 < 512 ? (n + 255) / 256 : 512);
     k_ray_bounds<<<rgrid, 256, 0, s>>>(d_pos, n, rb);
     const unsigned grid = (n + 255) / 256;
-    if (dir_is_i16) k_tile_keys<int16_t><<<grid, 256, 0, s>>>(d_pos, (const int16_t *)d_dir, n, rb, Bx, By, Bz, lpt, (uint32_t *)keys.p, (uint32_t *)vals.p);
-    else            k_tile_keys<float><<<grid, 256, 0, s>>>(d_pos, (const float *)d_dir, n, rb, Bx, By, Bz, lpt, (uint32_t *)keys.p, (uint32_t *)vals.p);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    size_t tmp_bytes = 0;
-    e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const uint32_t *)keys.p, (uint32_t *)keys_alt.p,
-                                  (const uint32_t *)vals.p, (uint32_t *)vals_alt.p, n, 0, 32, s);
-    if (e != hipSuccess) return e;
-    if ((e = tmp.reserve(tmp_bytes ? tmp_bytes : 16)) != hipSuccess) return e;
-    e = rocprim::radix_sort_pairs(tmp.p, tmp_bytes, (const uint32_t *)keys.p, (uint32_t *)keys_alt.p,
-                                  (const uint32_t *)vals.p, (uint32_t *)vals_alt.p, n, 0, lpt ? 32 : 29, s);
-    if (e != hipSuccess) return e;
+    const char *order_env = getenv("VRT_RAY_ORDER");                       // (development / tests: "radix" = the rocPRIM sort of rounds 1 and 2)
+    const bool use_radix = order_env && strcmp(order_env, "radix") == 0;
+    if (!lpt && !use_radix) {
+        // count per tile -> scan -> scatter -> order inside the tile (see k_tile_hist above)
+        if ((e = tmp.reserve(kTileBins * sizeof(uint32_t))) != hipSuccess) return e;
+        uint32_t *bins = (uint32_t *)tmp.p;
+        if ((e = hipMemsetAsync(bins, 0, kTileBins * sizeof(uint32_t), s)) != hipSuccess) return e;
+        if (dir_is_i16) k_tile_hist<int16_t><<<grid, 256, 0, s>>>(d_pos, (const int16_t *)d_dir, n, rb, Bx, By, Bz, (uint32_t *)keys.p, bins);
+        else            k_tile_hist<float><<<grid, 256, 0, s>>>(d_pos, (const float *)d_dir, n, rb, Bx, By, Bz, (uint32_t *)keys.p, bins);
+        k_tile_scan<<<1, 1024, 0, s>>>(bins);
+        k_tile_scatter<<<grid, 256, 0, s>>>((const uint32_t *)keys.p, n, bins, (uint32_t *)keys_alt.p, (uint32_t *)vals.p);
+        k_tile_order<<<kTileBins / 4u, 256, 0, s>>>(bins, (const uint32_t *)keys_alt.p, (const uint32_t *)vals.p, (uint32_t *)vals_alt.p);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    } else {
+        if (dir_is_i16) k_tile_keys<int16_t><<<grid, 256, 0, s>>>(d_pos, (const int16_t *)d_dir, n, rb, Bx, By, Bz, lpt, (uint32_t *)keys.p, (uint32_t *)vals.p);
+        else            k_tile_keys<float><<<grid, 256, 0, s>>>(d_pos, (const float *)d_dir, n, rb, Bx, By, Bz, lpt, (uint32_t *)keys.p, (uint32_t *)vals.p);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        // per-ray length buckets in the key (sort_rays = 2, opt-in): the general radix sort of the whole key
+        size_t tmp_bytes = 0;
+        e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const uint32_t *)keys.p, (uint32_t *)keys_alt.p,
+                                      (const uint32_t *)vals.p, (uint32_t *)vals_alt.p, n, 0, 32, s);
+        if (e != hipSuccess) return e;
+        if ((e = tmp.reserve(tmp_bytes ? tmp_bytes : 16)) != hipSuccess) return e;
+        e = rocprim::radix_sort_pairs(tmp.p, tmp_bytes, (const uint32_t *)keys.p, (uint32_t *)keys_alt.p,
+                                      (const uint32_t *)vals.p, (uint32_t *)vals_alt.p, n, 0, lpt ? 32 : 29, s);
+        if (e != hipSuccess) return e;
+    }
     *order_out = (const uint32_t *)vals_alt.p;
     if (wave_lpt && wave_order_out && field && inv && nw > 1) {
         // the ray sort's input buffers are free again: [0, nw) = wavefront keys / ids, [nw, 2 nw) = sorted
