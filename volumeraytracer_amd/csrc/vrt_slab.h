@@ -730,6 +730,13 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                 }
             }
 #endif
+            // Tried in round 3 and dropped: LANE WINDOWS for int16 fields -- every lane stages a private window of 5 layers along
+            // the wavefront's dominant axis x the 2 x 2 voxels around its ray (20 raw voxels = its 160 bytes of the segment, laid
+            // out so that the reads are conflict-free) and marches out of it: one memory round trip per window instead of one
+            // per step, and private windows cannot blow up the way a common brick does.  Bit-exact, but config 5 13.0 -> 28.4 -
+            // 32.5 ms: the rays that end up in these rounds are the strongly deflected ones, they cross a lateral cell boundary
+            // every 3 - 4 steps, so a window lasts a few steps and costs 20 scattered loads per lane (global-gather step 2 190 ->
+            // 5 750 wall cycles, and the staging of everybody else's bricks slowed from 3 980 to 9 750 per round behind them).
 #if VRT_PRIO_DIRECT
             __builtin_amdgcn_s_setprio(VRT_PRIO_DIRECT);
 #endif
