@@ -212,7 +212,8 @@ def reference_leg_child(path):
     np.savez(path + ".out.npz", end_position=out["end_position"], end_direction=out["end_direction"], end_iteration=out["end_iteration"])
     print(json.dumps({"seconds": max(dt - t_ctor, 1e-3), "seconds_with_constructor": dt, "constructor_seconds": t_ctor,
                       "ray_steps": int(out["end_iteration"].astype(np.int64).sum()),
-                      "threads": int(os.environ.get("OMP_NUM_THREADS", "0")) or os.cpu_count()}))
+                      # the reference runs min(omp_get_max_threads(), Options::_max_cpu = 256) threads (cuda_volume_raytracer.cu:809)
+                      "threads": min(oracle.port.num_threads(), 256)}))
 
 
 def reference_leg(host, tc_host, bounds, sp, sd, inv, iterations, port_out_for, budget_s, log):
