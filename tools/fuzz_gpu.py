@@ -98,6 +98,15 @@ def main():
         B, d, tc, sp, sd, inv, iters, opts, fdt, ddt = make_case(rng, args.big)
         field = oracle.port.interleave(d[0], d[1], d[2], tc)
         want = oracle.port.trace(field, B, sp, sd, inv, iters)
+        # round 3: the handle sometimes spans several engines (band cut + merge, on one device), the ray order is sometimes
+        # the radix sort of rounds 1 and 2 instead of the tile-count kernels
+        reps = int(rng.choice([0, 0, 2, 3]))
+        order = str(rng.choice(["tiles", "tiles", "radix"]))
+        os.environ.pop("VRT_DEBUG_REPLICAS", None)
+        if reps:
+            os.environ["VRT_DEBUG_REPLICAS"] = str(reps)
+        os.environ["VRT_RAY_ORDER"] = order
+        opts_desc = dict(opts, replicas=reps, order=order)
         try:
             with capi.Engine.from_host(B, d, tc) as eng:
                 got = eng.trace(sp, sd, inv, iters, options=capi.default_options(**opts))
@@ -112,7 +121,7 @@ def main():
         if bad:
             fails += 1
             print("FAIL case %d: %s  B=%s field=%s dir=%s rays=%d inv=%s iters=%d opts=%s rng-head=%s" %
-                  (cases, bad, B, fdt.__name__, ddt.__name__, sp.size // 3, inv, iters, opts, state), flush=True)
+                  (cases, bad, B, fdt.__name__, ddt.__name__, sp.size // 3, inv, iters, opts_desc, state), flush=True)
         if cases % 200 == 0:
             print("... %d cases, %d failures, %.3g ray-steps, %.0f s" % (cases, fails, steps, time.time() - t0), flush=True)
     print("fuzz: %d cases, %d failures, %.3g ray-steps checked in %.0f s (seed %d)" % (cases, fails, steps, time.time() - t0, args.seed))
