@@ -12,7 +12,7 @@ import json
 import os
 import sys
 
-KEEP = ("k_march", "k_tile", "k_bounds_init", "k_interleave", "radix", "onesweep", "rocprim", "k_wave_work", "k_ray_bounds", "k_scene_build",
+KEEP = ("k_march", "k_tile", "k_bounds_finish", "k_interleave", "radix", "onesweep", "rocprim", "k_wave_work", "k_ray_bounds", "k_scene_build",
         "k_ray_prologue", "k_field_absmax", "k_absmax_reduce", "k_wave_sort")
 
 

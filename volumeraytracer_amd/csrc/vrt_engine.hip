@@ -507,6 +507,25 @@ int trace_device_impl(vrt_engine *e, Workspace &w, int dir_type, size_t nrays, c
 
     // tile ordering: group rays that enter the field close together into the same wavefront
     const bool sort = o.sort_rays > 0 || (o.sort_rays == 0 && nrays >= 4096);
+    // What the march needs zeroed per call -- the scheduler's counters, its queue ring, the clock words -- is zeroed by the
+    // ray order's first kernel when there is one (vrt_sort.h, ZeroList): each was a hipMemsetAsync, i.e. a small launch, of its own.
+    const size_t groups_all = (nrays + 63) / 64;
+    unsigned long long ring_words = 64;                  // ring of re-queued groups: a power of two >= 2 x groups
+    while (ring_words < 2ull * groups_all) ring_words <<= 1;
+    bool zeroed = false, zeroed_ring = false;
+    vrt::ZeroList zl = {{nullptr, nullptr, nullptr, nullptr}, {0u, 0u, 0u, 0u}};
+    if (sort) {
+        HIP_TRY(w.group_ctr.reserve(vrt::kCtrWords * sizeof(uint32_t)));
+        HIP_TRY(w.clock.reserve(4 * sizeof(unsigned long long)));
+        zl.p[0] = (uint32_t *)w.group_ctr.p; zl.words[0] = vrt::kCtrWords;
+        zl.p[1] = (uint32_t *)w.clock.p;     zl.words[1] = 8u;
+        zeroed = true;
+        if (kernel == VRT_KERNEL_SLAB && geo.complete && groups_all > 1 && !p.transl && ring_words <= 0xFFFFFFFFull) {
+            HIP_TRY(w.slice_flags.reserve_uncached((size_t)ring_words * sizeof(uint32_t)));
+            zl.p[2] = (uint32_t *)w.slice_flags.p; zl.words[2] = (uint32_t)ring_words;
+            zeroed_ring = true;
+        }
+    }
     if (sort) {
         Range range("vrt: ray order");
         const uint32_t *order = nullptr, *wave_order = nullptr;
@@ -515,7 +534,7 @@ int trace_device_impl(vrt_engine *e, Workspace &w, int dir_type, size_t nrays, c
         const int wave_lpt = !d_path && (o.sort_rays == 3 || (o.sort_rays == 0 && (nrays + 63) / 64 > resident_waves));
         hipError_t se = vrt::build_tile_order(d_sp, d_sd, dir_type, (uint32_t)nrays, e->B[0], e->B[1], e->B[2], o.sort_rays == 2 ? 1 : 0, w.sort_keys, w.sort_keys_alt,
                                               w.sort_vals, w.sort_vals_alt, w.sort_tmp, w.sort_bounds, s, &order,
-                                              wave_lpt, iterations, &wave_order, e->field, e->field_type == VRT_I16, invscale);
+                                              wave_lpt, iterations, &wave_order, e->field, e->field_type == VRT_I16, invscale, &zl);
         if (se != hipSuccess) return fail(se == hipErrorOutOfMemory ? VRT_ERR_OUT_OF_MEMORY : VRT_ERR_HIP,
                                           "ray tile ordering failed: %s", hipGetErrorString(se));
         p.order = order;
@@ -588,7 +607,7 @@ int trace_device_impl(vrt_engine *e, Workspace &w, int dir_type, size_t nrays, c
         launched_schedule = kernel == VRT_KERNEL_SLAB ? 1 : 0;
         if (schedule >= 2 && kernel == VRT_KERNEL_SLAB && groups > 1 && geo.complete) {
             HIP_TRY(w.group_ctr.reserve(vrt::kCtrWords * sizeof(uint32_t)));
-            HIP_TRY(hipMemsetAsync(w.group_ctr.p, 0, vrt::kCtrWords * sizeof(uint32_t), s));
+            if (!zeroed) HIP_TRY(hipMemsetAsync(w.group_ctr.p, 0, vrt::kCtrWords * sizeof(uint32_t), s));
             p.group_counter = (uint32_t *)w.group_ctr.p;
             tuner_trial = trial;
             launched_schedule = 2;
@@ -602,11 +621,10 @@ int trace_device_impl(vrt_engine *e, Workspace &w, int dir_type, size_t nrays, c
                 if (const char *ev = getenv("VRT_SLICE_PERCENT")) p.slice_percent = (uint32_t)std::max(10L, strtol(ev, nullptr, 10));
                 if (p.wave_order) p.work_sum = &((const vrt::RayBounds *)w.sort_bounds.p)->work_sum;
                 // ring of re-queued groups: a power of two >= 2 x groups (at most one word per group is ever occupied)
-                unsigned long long cap = 64;
-                while (cap < 2ull * groups) cap <<= 1;
+                const unsigned long long cap = ring_words;
                 HIP_TRY(w.park.reserve_uncached(groups * 2048));
                 HIP_TRY(w.slice_flags.reserve_uncached((size_t)cap * sizeof(uint32_t)));
-                HIP_TRY(hipMemsetAsync(w.slice_flags.p, 0, (size_t)cap * sizeof(uint32_t), s));
+                if (!zeroed_ring) HIP_TRY(hipMemsetAsync(w.slice_flags.p, 0, (size_t)cap * sizeof(uint32_t), s));
                 p.park = w.park.p;
                 p.slice_flags = (uint32_t *)w.slice_flags.p;
                 p.slice_steps = slice;
@@ -618,7 +636,7 @@ int trace_device_impl(vrt_engine *e, Workspace &w, int dir_type, size_t nrays, c
     // one wavefront of the march stamps (s_memtime, s_memrealtime) when it starts and when it ends: the clock the
     // kernel really ran at, for the roofline's peak (vrt_engine_last_march_clock_ghz)
     HIP_TRY(w.clock.reserve(4 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(w.clock.p, 0, 4 * sizeof(unsigned long long), s));
+    if (!zeroed) HIP_TRY(hipMemsetAsync(w.clock.p, 0, 4 * sizeof(unsigned long long), s));
     p.clock_out = (unsigned long long *)w.clock.p;
 
     Range range("vrt: march");

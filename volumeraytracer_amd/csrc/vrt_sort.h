@@ -27,19 +27,25 @@ struct RayBounds {          // filled on the device, consumed on the device: no 
     unsigned long long work_sum;   // k_wave_work: sum of the wavefronts' work estimates (coarse steps); read by the time-sliced march
 };
 
-__global__ void k_bounds_init(RayBounds *b)
-{
-    if (threadIdx.x < 3) { b->lo[threadIdx.x] = 0xFFFFFFFFu; b->hi[threadIdx.x] = 0u; }
-    if (threadIdx.x == 3) b->work_sum = 0ull;
-}
+// ---- round 3: the same bounds without an init kernel, without atomics and with the call's memsets folded in --------------
+// Every workgroup writes its own six words (`partial[block]`); whoever needs the bounds next (k_tile_hist, k_bounds_finish)
+// folds the at most kBoundsBlocks partials itself -- 6 x 256 words out of L2, cheaper than 6 contended atomics per workgroup
+// and one launch less (k_bounds_init).  The same kernel zeroes what the rest of the call needs zeroed: the tile bins and, for the
+// engine, the scheduler's counters / queue ring / clock words (ZeroList) -- each of those was a hipMemsetAsync of its own, five
+// small launches per call, as many as the ray order has kernels.
+constexpr uint32_t kBoundsBlocks = 256;
+struct ZeroList { uint32_t *p[4]; uint32_t words[4]; };
+struct BoundsPartial { uint32_t lo[3], hi[3]; };
 
-__global__ __launch_bounds__(256) void k_ray_bounds(const uint32_t *pos, uint32_t n, RayBounds *b)
+__global__ __launch_bounds__(256) void k_ray_bounds_partial(const uint32_t *pos, uint32_t n, BoundsPartial *partial, const ZeroList z)
 {
-    // one atomic per block and component: with one per wavefront, 4096 wavefronts hammering six addresses
-    // took 280 us for 12 MB of input (the atomics serialise)
+    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, gsize = gridDim.x * blockDim.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        for (uint32_t i = gtid; i < z.words[k]; i += gsize) z.p[k][i] = 0u;
     __shared__ uint32_t s_lo[4][3], s_hi[4][3];
     uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (uint32_t i = gtid; i < n; i += gsize) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const uint32_t v = pos[3 * (size_t)i + d];
@@ -61,9 +67,42 @@ __global__ __launch_bounds__(256) void k_ray_bounds(const uint32_t *pos, uint32_
         const int d = threadIdx.x;
         uint32_t l = s_lo[0][d], h = s_hi[0][d];
         for (int w = 1; w < 4; ++w) { l = s_lo[w][d] < l ? s_lo[w][d] : l; h = s_hi[w][d] > h ? s_hi[w][d] : h; }
-        atomicMin(&b->lo[d], l);
-        atomicMax(&b->hi[d], h);
+        partial[blockIdx.x].lo[d] = l;
+        partial[blockIdx.x].hi[d] = h;
     }
+}
+
+// fold the partials (one workgroup of 256 threads, nparts <= kBoundsBlocks) into `out` (LDS or global), work_sum = 0
+__device__ __forceinline__ void fold_bounds(const BoundsPartial *partial, uint32_t nparts, RayBounds *out, uint32_t (*s_red)[6])
+{
+    const uint32_t t = threadIdx.x;
+    uint32_t v[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+    if (t < nparts) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { v[d] = partial[t].lo[d]; v[3 + d] = partial[t].hi[d]; }
+    }
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t a = __shfl_xor(v[d], o);
+            v[d] = d < 3 ? (a < v[d] ? a : v[d]) : (a > v[d] ? a : v[d]);
+        }
+        if ((t & 63u) == 0) s_red[t >> 6][d] = v[d];
+    }
+    __syncthreads();
+    if (t < 6) {
+        uint32_t r = s_red[0][t];
+        for (int w = 1; w < 4; ++w) r = t < 3 ? (s_red[w][t] < r ? s_red[w][t] : r) : (s_red[w][t] > r ? s_red[w][t] : r);
+        if (t < 3) out->lo[t] = r; else out->hi[t - 3] = r;
+    }
+    if (t == 6) out->work_sum = 0ull;
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_bounds_finish(const BoundsPartial *partial, uint32_t nparts, RayBounds *rb)
+{
+    __shared__ uint32_t s_red[4][6];
+    fold_bounds(partial, nparts, rb, s_red);
 }
 
 // 32-bit key, most significant first:
@@ -168,9 +207,19 @@ __device__ __forceinline__ LaneRun run_of(uint32_t bin, bool valid)
 }
 
 template <typename DirT>
-__global__ __launch_bounds__(256) void k_tile_hist(const uint32_t *pos, const DirT *dir, uint32_t n, const RayBounds *rb, uint32_t Bx,
-                                                   uint32_t By, uint32_t Bz, uint32_t *keys, uint32_t *bins)
+__global__ __launch_bounds__(256) void k_tile_hist(const uint32_t *pos, const DirT *dir, uint32_t n, const BoundsPartial *partial,
+                                                   uint32_t nparts, RayBounds *rb_out, uint32_t Bx, uint32_t By, uint32_t Bz, uint32_t *keys,
+                                                   uint32_t *bins)
 {
+    __shared__ RayBounds s_rb;
+    __shared__ uint32_t s_red[4][6];
+    fold_bounds(partial, nparts, &s_rb, s_red);            // every workgroup folds the bounds for itself ...
+    if (blockIdx.x == 0 && threadIdx.x < 7) {              // ... and the first leaves them (and a zeroed work sum) for the later kernels
+        if (threadIdx.x < 3) rb_out->lo[threadIdx.x] = s_rb.lo[threadIdx.x];
+        else if (threadIdx.x < 6) rb_out->hi[threadIdx.x - 3] = s_rb.hi[threadIdx.x - 3];
+        else rb_out->work_sum = 0ull;
+    }
+    const RayBounds *rb = &s_rb;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n;
     uint32_t key = 0;
@@ -179,65 +228,74 @@ __global__ __launch_bounds__(256) void k_tile_hist(const uint32_t *pos, const Di
     if (valid && r.place == 0u) atomicAdd(&bins[tile_bin(key)], r.length);
 }
 
-// exclusive scan of the 65 536 tile counts, in place, by one workgroup (64 bins per thread)
-__global__ __launch_bounds__(1024) void k_tile_scan(uint32_t *bins)
+// Exclusive scan of the 65 536 tile counts in two levels: kScanBlocks workgroups scan 1 024 bins each in place and leave their
+// totals; the two consumers (scatter, in-tile order) add the prefix of the totals themselves (64 words: one wavefront reduction).
+// (One workgroup scanning all bins took 18 us: the largest kernel of the chain after the pre-march.)
+constexpr uint32_t kScanBlocks = 64, kScanPer = kTileBins / kScanBlocks;      // 1 024 bins per workgroup, one per thread
+__global__ __launch_bounds__(1024) void k_tile_scan(uint32_t *bins, uint32_t *totals)
 {
-    constexpr uint32_t kPer = kTileBins / 1024u;
     __shared__ uint32_t wsum[16];
     const uint32_t tid = threadIdx.x;
-    uint32_t loc[kPer], tot = 0;
-    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    u4 *vb = (u4 *)(bins + tid * kPer);                   // 64 consecutive words per thread: 16-byte accesses
-#pragma unroll
-    for (uint32_t j = 0; j < kPer / 4u; ++j) {
-        const u4 v = vb[j];
-        loc[4 * j] = v.x; loc[4 * j + 1] = v.y; loc[4 * j + 2] = v.z; loc[4 * j + 3] = v.w;
-        tot += (v.x + v.y) + (v.z + v.w);
-    }
-    uint32_t incl = tot;
+    uint32_t *b = bins + blockIdx.x * kScanPer;
+    const uint32_t mine = b[tid];
+    uint32_t incl = mine;
     for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o); if ((tid & 63u) >= (uint32_t)o) incl += t; }
     if ((tid & 63u) == 63u) wsum[tid >> 6] = incl;
     __syncthreads();
-    uint32_t run = incl - tot;
-    for (uint32_t w = 0; w < (tid >> 6); ++w) run += wsum[w];
-#pragma unroll
-    for (uint32_t j = 0; j < kPer / 4u; ++j) {
-        u4 v;
-        v.x = run; run += loc[4 * j];
-        v.y = run; run += loc[4 * j + 1];
-        v.z = run; run += loc[4 * j + 2];
-        v.w = run; run += loc[4 * j + 3];
-        vb[j] = v;
-    }
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < (tid >> 6); ++w) base += wsum[w];
+    b[tid] = base + incl - mine;
+    if (tid == 1023u) totals[blockIdx.x] = base + incl;
+}
+// first slot of scan block `blk`: the sum of the totals of the blocks before it (all 64 lanes of the wavefront take part)
+__device__ __forceinline__ uint32_t scan_base(const uint32_t *totals, uint32_t blk)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t v = lane < blk ? totals[lane] : 0u;
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
+    return v;
 }
 
-// every ray to its tile's segment; the bin's word ends up as the segment's END (the next bin's start)
-__global__ __launch_bounds__(256) void k_tile_scatter(const uint32_t *keys, uint32_t n, uint32_t *bins, uint32_t *sub_out, uint32_t *ray_out)
+// every ray to its tile's segment; the bin's word ends up as the segment's END relative to its scan block (the next bin's start)
+__global__ __launch_bounds__(256) void k_tile_scatter(const uint32_t *keys, uint32_t n, uint32_t *bins, const uint32_t *totals,
+                                                      uint32_t *sub_out, uint32_t *ray_out)
 {
+    __shared__ uint32_t s_base[kScanBlocks];
+    if (threadIdx.x < 64u) {                               // exclusive prefix of the 64 totals, once per workgroup
+        const uint32_t t = totals[threadIdx.x];
+        uint32_t incl = t;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)incl, o); if (threadIdx.x >= (uint32_t)o) incl += u; }
+        s_base[threadIdx.x] = incl - t;
+    }
+    __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n;
     const uint32_t key = valid ? keys[i] : 0u;
-    const LaneRun r = run_of(tile_bin(key), valid);
+    const uint32_t bin = tile_bin(key);
+    const LaneRun r = run_of(bin, valid);
     uint32_t base = 0;
-    if (valid && r.place == 0u) base = atomicAdd(&bins[tile_bin(key)], r.length);       // one atomic per run of equal tiles
+    if (valid && r.place == 0u) base = atomicAdd(&bins[bin], r.length);       // one atomic per run of equal tiles
     base = (uint32_t)__shfl((int)base, (int)r.first);
     if (!valid) return;
-    const uint32_t at = base + r.place;
+    const uint32_t at = s_base[bin / kScanPer] + base + r.place;
     sub_out[at] = tile_sub(key);
     ray_out[at] = i;
 }
 
 // one wavefront per tile: rank of every ray of the segment by (in-tile key, position in the segment) -- unique, so the
 // rank is the number of smaller ones -- counted against the segment's keys in LDS
-__global__ __launch_bounds__(256) void k_tile_order(const uint32_t *bins, const uint32_t *sub, const uint32_t *ray, uint32_t *order)
+__global__ __launch_bounds__(256) void k_tile_order(const uint32_t *bins, const uint32_t *totals, const uint32_t *sub, const uint32_t *ray,
+                                                    uint32_t *order)
 {
     __shared__ uint32_t s_key[4][kTileSortMax];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t bin = blockIdx.x * 4u + wave;
-    const uint32_t end = bins[bin], start = bin ? bins[bin - 1u] : 0u;
-    const uint32_t cnt = end - start;
-    if (cnt == 0u) return;
-    if (cnt > kTileSortMax) {                              // (wave-uniform) copy through
+    const uint32_t blk = bin / kScanPer;
+    const uint32_t end_rel = bins[bin], start_rel = (bin % kScanPer) ? bins[bin - 1u] : 0u;   // relative to the scan block
+    const uint32_t cnt = end_rel - start_rel;
+    if (cnt == 0u) return;                                 // (wave-uniform)
+    const uint32_t start = scan_base(totals, blk) + start_rel;
+    if (cnt > kTileSortMax) {                              // copy through
         for (uint32_t e = lane; e < cnt; e += 64u) order[start + e] = ray[start + e];
         return;
     }
@@ -280,14 +338,22 @@ __global__ __launch_bounds__(256) void k_wave_work(const typename FieldTraits<Fi
                                                    uint32_t By, uint32_t Bz, float invx, float invy, float invz,
                                                    uint32_t iterations, uint32_t *wkeys, uint32_t *wvals, RayBounds *rb)
 {
+    // (Round 3: sampling an 8 x coarser copy of the field that fits the L2 instead -- the pre-march is a chain of dependent
+    // samples, one memory latency each -- cut this kernel from 62 to 40 us, but the launch order it produced was worse: the
+    // march of config 5 ran 2 % longer (13.1 vs 12.85 ms), config 3's the same.  Not kept.)
+#ifndef VRT_WW_REPS_LOG2
+#define VRT_WW_REPS_LOG2 2
+#endif
+    constexpr uint32_t kRepsLog2 = VRT_WW_REPS_LOG2, kReps = 1u << kRepsLog2;      // representative rays per wavefront (4)
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t w = t >> 2, nw = (n + 63u) >> 6;
+    const uint32_t w = t >> kRepsLog2, nw = (n + 63u) >> 6;
     __shared__ uint32_t s_sum;
     if (threadIdx.x == 0) s_sum = 0u;
     __syncthreads();
     const bool valid = w < nw;                             // (threads past the end idle through the loop: the block meets again below)
-    const uint32_t rep[4] = {5u, 23u, 40u, 58u};
-    uint32_t slot = (valid ? w : nw - 1u) * 64u + rep[t & 3u];
+    // spread over the tile: rows 0 / 2 / 5 / 7 of the 8 x 8 tile for four, every row for eight
+    const uint32_t rep_slot = kReps == 4u ? (uint32_t[4]){5u, 23u, 40u, 58u}[t & 3u] : ((t & (kReps - 1u)) * (64u / kReps) + ((t * 5u) & (64u / kReps - 1u)));
+    uint32_t slot = (valid ? w : nw - 1u) * 64u + rep_slot;
     slot = slot < n ? slot : n - 1u;
     const uint32_t i = order ? order[slot] : slot;
     float px = (float)pos[3 * (size_t)i], py = (float)pos[3 * (size_t)i + 1], pz = (float)pos[3 * (size_t)i + 2];
@@ -317,9 +383,9 @@ __global__ __launch_bounds__(256) void k_wave_work(const typename FieldTraits<Fi
     }
     // a wavefront marches until its last ray stops: the largest of the four estimates.  (Weighting steps the
     // planner would have to gather from global memory by 1.5 was tried and ordered no better.)
-    est = max(est, (uint32_t)__shfl_xor((int)est, 1));
-    est = max(est, (uint32_t)__shfl_xor((int)est, 2));
-    if (valid && (t & 3u) == 0) {
+#pragma unroll
+    for (uint32_t o = 1; o < kReps; o <<= 1) est = max(est, (uint32_t)__shfl_xor((int)est, (int)o));
+    if (valid && (t & (kReps - 1u)) == 0) {
         wkeys[w] = (uint32_t)kCoarseMaxLoops - (est >> VRT_LPT_SHIFT);     // ascending sort = longest first; est <= kCoarseMaxLoops: 12 key bits
         wvals[w] = w;
         atomicAdd(&s_sum, est);                            // LDS: 64 adds per block, then one global atomic per block
@@ -383,7 +449,7 @@ hipError_t build_tile_order(const uint32_t *d_pos, const void *d_dir, int dir_is
                             Buf &keys_alt, Buf &vals, Buf &vals_alt, Buf &tmp, Buf &bounds, hipStream_t s,
                             const uint32_t **order_out, int wave_lpt = 0, uint32_t iterations = 0,
                             const uint32_t **wave_order_out = nullptr, const void *field = nullptr, int field_is_i16 = 0,
-                            const float *inv = nullptr)
+                            const float *inv = nullptr, const ZeroList *also_zero = nullptr)
 {
     hipError_t e;
     const uint32_t nw = (n + 63u) >> 6;
@@ -392,26 +458,32 @@ hipError_t build_tile_order(const uint32_t *d_pos, const void *d_dir, int dir_is
     if ((e = keys_alt.reserve((size_t)n * 4)) != hipSuccess) return e;
     if ((e = vals.reserve(kbytes)) != hipSuccess) return e;
     if ((e = vals_alt.reserve((size_t)n * 4)) != hipSuccess) return e;
-    if ((e = bounds.reserve(sizeof(RayBounds))) != hipSuccess) return e;
+    // bounds buffer: the RayBounds the later kernels read, then the per-workgroup partials
+    constexpr size_t kPartialOff = 64;
+    if ((e = bounds.reserve(kPartialOff + kBoundsBlocks * sizeof(BoundsPartial))) != hipSuccess) return e;
     RayBounds *rb = (RayBounds *)bounds.p;
-    k_bounds_init<<<1, 64, 0, s>>>(rb);
-    const unsigned rgrid = (unsigned)((n + 255) / 256 < 512 ? (n + 255) / 256 : 512);
-    k_ray_bounds<<<rgrid, 256, 0, s>>>(d_pos, n, rb);
+    BoundsPartial *partial = (BoundsPartial *)((char *)bounds.p + kPartialOff);
+    const unsigned rgrid = (unsigned)((n + 255) / 256 < kBoundsBlocks ? (n + 255) / 256 : kBoundsBlocks);
     const unsigned grid = (n + 255) / 256;
     const char *order_env = getenv("VRT_RAY_ORDER");                       // (development / tests: "radix" = the rocPRIM sort of rounds 1 and 2)
     const bool use_radix = order_env && strcmp(order_env, "radix") == 0;
+    ZeroList z = {{nullptr, nullptr, nullptr, nullptr}, {0u, 0u, 0u, 0u}};
+    if (also_zero) z = *also_zero;                         // slots 0..2: the engine's scheduler words; slot 3: the tile bins
     if (!lpt && !use_radix) {
-        // count per tile -> scan -> scatter -> order inside the tile (see k_tile_hist above)
-        if ((e = tmp.reserve(kTileBins * sizeof(uint32_t))) != hipSuccess) return e;
-        uint32_t *bins = (uint32_t *)tmp.p;
-        if ((e = hipMemsetAsync(bins, 0, kTileBins * sizeof(uint32_t), s)) != hipSuccess) return e;
-        if (dir_is_i16) k_tile_hist<int16_t><<<grid, 256, 0, s>>>(d_pos, (const int16_t *)d_dir, n, rb, Bx, By, Bz, (uint32_t *)keys.p, bins);
-        else            k_tile_hist<float><<<grid, 256, 0, s>>>(d_pos, (const float *)d_dir, n, rb, Bx, By, Bz, (uint32_t *)keys.p, bins);
-        k_tile_scan<<<1, 1024, 0, s>>>(bins);
-        k_tile_scatter<<<grid, 256, 0, s>>>((const uint32_t *)keys.p, n, bins, (uint32_t *)keys_alt.p, (uint32_t *)vals.p);
-        k_tile_order<<<kTileBins / 4u, 256, 0, s>>>(bins, (const uint32_t *)keys_alt.p, (const uint32_t *)vals.p, (uint32_t *)vals_alt.p);
+        // bounds (+ the call's zeroing) -> count per tile -> scan -> scatter -> order inside the tile (see k_tile_hist above)
+        if ((e = tmp.reserve((kTileBins + kScanBlocks) * sizeof(uint32_t))) != hipSuccess) return e;
+        uint32_t *bins = (uint32_t *)tmp.p, *totals = bins + kTileBins;
+        z.p[3] = bins; z.words[3] = kTileBins;
+        k_ray_bounds_partial<<<rgrid, 256, 0, s>>>(d_pos, n, partial, z);
+        if (dir_is_i16) k_tile_hist<int16_t><<<grid, 256, 0, s>>>(d_pos, (const int16_t *)d_dir, n, partial, rgrid, rb, Bx, By, Bz, (uint32_t *)keys.p, bins);
+        else            k_tile_hist<float><<<grid, 256, 0, s>>>(d_pos, (const float *)d_dir, n, partial, rgrid, rb, Bx, By, Bz, (uint32_t *)keys.p, bins);
+        k_tile_scan<<<kScanBlocks, 1024, 0, s>>>(bins, totals);
+        k_tile_scatter<<<grid, 256, 0, s>>>((const uint32_t *)keys.p, n, bins, totals, (uint32_t *)keys_alt.p, (uint32_t *)vals.p);
+        k_tile_order<<<kTileBins / 4u, 256, 0, s>>>(bins, totals, (const uint32_t *)keys_alt.p, (const uint32_t *)vals.p, (uint32_t *)vals_alt.p);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     } else {
+        k_ray_bounds_partial<<<rgrid, 256, 0, s>>>(d_pos, n, partial, z);
+        k_bounds_finish<<<1, 256, 0, s>>>(partial, rgrid, rb);
         if (dir_is_i16) k_tile_keys<int16_t><<<grid, 256, 0, s>>>(d_pos, (const int16_t *)d_dir, n, rb, Bx, By, Bz, lpt, (uint32_t *)keys.p, (uint32_t *)vals.p);
         else            k_tile_keys<float><<<grid, 256, 0, s>>>(d_pos, (const float *)d_dir, n, rb, Bx, By, Bz, lpt, (uint32_t *)keys.p, (uint32_t *)vals.p);
         if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -430,7 +502,7 @@ hipError_t build_tile_order(const uint32_t *d_pos, const void *d_dir, int dir_is
         // the ray sort's input buffers are free again: [0, nw) = wavefront keys / ids, [nw, 2 nw) = sorted
         uint32_t *wk = (uint32_t *)keys.p, *wv = (uint32_t *)vals.p;
         const uint32_t *ord = (const uint32_t *)vals_alt.p;
-        const unsigned wgrid = (4u * nw + 255u) / 256u;
+        const unsigned wgrid = ((nw << VRT_WW_REPS_LOG2) + 255u) / 256u;
         using vf = const FieldTraits<float>::vox *;
         using vi = const FieldTraits<int16_t>::vox *;
 #define VRT_WW(FT, DT, FP) k_wave_work<FT, DT><<<wgrid, 256, 0, s>>>((FP)field, d_pos, (const DT *)d_dir, ord, n, Bx, By, Bz, \
