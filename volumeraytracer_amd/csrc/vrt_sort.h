@@ -328,6 +328,14 @@ __global__ __launch_bounds__(256) void k_tile_order(const uint32_t *bins, const 
 #endif
 constexpr int kCoarse = VRT_COARSE;  // fine steps per coarse step
 constexpr int kCoarseMaxLoops = 2048;
+// Work key of a wavefront: its estimate in half coarse steps (an LDS step counts 2, see VRT_WW_GLOBAL_W), clamped.
+constexpr int kWaveKeyMax = 8192;
+#ifndef VRT_WW_SPREAD_VOX
+#define VRT_WW_SPREAD_VOX 0          // 0 = every coarse step counts the same
+#endif
+#ifndef VRT_WW_GLOBAL_W
+#define VRT_WW_GLOBAL_W 5
+#endif
 #ifndef VRT_LPT_SHIFT
 #define VRT_LPT_SHIFT 0
 #endif
@@ -342,9 +350,13 @@ __global__ __launch_bounds__(256) void k_wave_work(const typename FieldTraits<Fi
     // samples, one memory latency each -- cut this kernel from 62 to 40 us, but the launch order it produced was worse: the
     // march of config 5 ran 2 % longer (13.1 vs 12.85 ms), config 3's the same.  Not kept.)
 #ifndef VRT_WW_REPS_LOG2
-#define VRT_WW_REPS_LOG2 2
+#define VRT_WW_REPS_LOG2 4
 #endif
-    constexpr uint32_t kRepsLog2 = VRT_WW_REPS_LOG2, kReps = 1u << kRepsLog2;      // representative rays per wavefront (4)
+    // Representative rays per wavefront: 16 (rounds 1 and 2: 4).  The estimate is the maximum over them, and how well it ranks the
+    // wavefronts shows in the march itself (MI355X, kernel ms, config 5 / config 3): 4 rays 13.28 / 6.95, 8 rays 12.69 / 6.91,
+    // 16 rays 12.42 / 6.87, 32 rays 12.9 - 13.0 / 7.1, all 64 12.68 / 7.05 with the whole step 0.9 ms slower (the pre-march then
+    // costs more than it returns).  The slice length (1.15 x the mean estimate) was swept again with 16: still the optimum.
+    constexpr uint32_t kRepsLog2 = VRT_WW_REPS_LOG2, kReps = 1u << kRepsLog2;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t w = t >> kRepsLog2, nw = (n + 63u) >> 6;
     __shared__ uint32_t s_sum;
@@ -364,29 +376,53 @@ __global__ __launch_bounds__(256) void k_wave_work(const typename FieldTraits<Fi
     const uint32_t loops_max = cap < (uint32_t)kCoarseMaxLoops ? cap : (uint32_t)kCoarseMaxLoops;
     const float m = (float)kCoarse;
     bool alive = valid;
-    uint32_t est = 0;                                     // coarse steps until the last representative stops
+    uint32_t est = 0;                                     // coarse steps until this representative stops
+    uint32_t tw = 0;                                      // the wavefront's estimated TIME, in half LDS steps (same in all lanes of a group)
+    constexpr bool kSpread = VRT_WW_SPREAD_VOX > 0;
     for (uint32_t loops = 0; loops < loops_max; ++loops) {
         alive = alive && px >= 0.0f && py >= 0.0f && pz >= 0.0f && px < hx && py < hy && pz < hz;   // false on NaN
-        if (!alive) break;
-        const uint32_t cx = (uint32_t)(px * (1.0f / 65536.0f)), cy = (uint32_t)(py * (1.0f / 65536.0f)), cz = (uint32_t)(pz * (1.0f / 65536.0f));
-        f4 g;
-        cvt_vox(field[((size_t)cx * By + cy) * Bz + cz], g);
-        if (g.w > 0.0f) break;
-        dx = fmaf(g.x * m, invx, dx);
-        dy = fmaf(g.y * m, invy, dy);
-        dz = fmaf(g.z * m, invz, dz);
-        const float il = m * 0x42000000p0f / (dx * dx + dy * dy + dz * dz);
-        px = fmaf(dx * invx, il, px);
-        py = fmaf(dy * invy, il, py);
-        pz = fmaf(dz * invz, il, pz);
-        ++est;
+        if (alive) {
+            const uint32_t cx = (uint32_t)(px * (1.0f / 65536.0f)), cy = (uint32_t)(py * (1.0f / 65536.0f)), cz = (uint32_t)(pz * (1.0f / 65536.0f));
+            f4 g;
+            cvt_vox(field[((size_t)cx * By + cy) * Bz + cz], g);
+            if (g.w > 0.0f) alive = false;
+            else {
+                dx = fmaf(g.x * m, invx, dx);
+                dy = fmaf(g.y * m, invy, dy);
+                dz = fmaf(g.z * m, invz, dz);
+                const float il = m * 0x42000000p0f / (dx * dx + dy * dy + dz * dz);
+                px = fmaf(dx * invx, il, px);
+                py = fmaf(dy * invy, il, py);
+                pz = fmaf(dz * invz, il, pz);
+                ++est;
+            }
+        }
+        if (__ballot(alive) == 0ull) break;               // (the four groups of a wavefront of this kernel leave together)
+        if constexpr (kSpread) {
+            // how far apart are the group's representatives?  When their bounding box (plus the trilinear halo) outgrows a brick
+            // the wavefront will be gathering from global memory, at about 2.4 x the cost of a step out of LDS
+            float lo[3] = {alive ? px : 3.0e38f, alive ? py : 3.0e38f, alive ? pz : 3.0e38f};
+            float hi[3] = {alive ? px : -3.0e38f, alive ? py : -3.0e38f, alive ? pz : -3.0e38f};
+#pragma unroll
+            for (uint32_t o = 1; o < kReps; o <<= 1)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    lo[d] = fminf(lo[d], __shfl_xor(lo[d], (int)o));
+                    hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], (int)o));
+                }
+            if (hi[0] >= lo[0]) {
+                const float vol = ((hi[0] - lo[0]) * (1.0f / 65536.0f) + 2.0f) * ((hi[1] - lo[1]) * (1.0f / 65536.0f) + 2.0f) * ((hi[2] - lo[2]) * (1.0f / 65536.0f) + 2.0f);
+                tw += vol > (float)VRT_WW_SPREAD_VOX ? (uint32_t)VRT_WW_GLOBAL_W : 2u;
+            }
+        }
     }
-    // a wavefront marches until its last ray stops: the largest of the four estimates.  (Weighting steps the
-    // planner would have to gather from global memory by 1.5 was tried and ordered no better.)
+    // a wavefront marches until its last ray stops: the largest of the representatives' estimates
 #pragma unroll
     for (uint32_t o = 1; o < kReps; o <<= 1) est = max(est, (uint32_t)__shfl_xor((int)est, (int)o));
+    if constexpr (!kSpread) tw = 2u * est;
     if (valid && (t & (kReps - 1u)) == 0) {
-        wkeys[w] = (uint32_t)kCoarseMaxLoops - (est >> VRT_LPT_SHIFT);     // ascending sort = longest first; est <= kCoarseMaxLoops: 12 key bits
+        const uint32_t k = (tw >> VRT_LPT_SHIFT) < (uint32_t)kWaveKeyMax ? (tw >> VRT_LPT_SHIFT) : (uint32_t)kWaveKeyMax;
+        wkeys[w] = (uint32_t)kWaveKeyMax - k;              // ascending sort = longest first
         wvals[w] = w;
         atomicAdd(&s_sum, est);                            // LDS: 64 adds per block, then one global atomic per block
     }
@@ -394,14 +430,14 @@ __global__ __launch_bounds__(256) void k_wave_work(const typename FieldTraits<Fi
     if (threadIdx.x == 0) atomicAdd(&rb->work_sum, (unsigned long long)s_sum);
 }
 
-// Launch order of the wavefronts from their work keys (kCoarseMaxLoops - estimate, 12 bits): ONE workgroup sorts them by
-// counting in LDS -- histogram with LDS atomics, scan of the 2049 bins, scatter.  (Rounds 1 and 2 called rocPRIM's radix sort
+// Launch order of the wavefronts from their work keys (kWaveKeyMax - estimate, 13 bits): ONE workgroup sorts them by
+// counting in LDS -- histogram with LDS atomics, scan of the 8 193 bins, scatter.  (Rounds 1 and 2 called rocPRIM's radix sort
 // here: six to eight small dependent launches, about 40 us plus their gaps, for 16 384 keys.)  Ties come out in arbitrary
 // order: the launch order is a scheduling hint, results never depend on it.
 constexpr int kWaveSortThreads = 1024;
 __global__ __launch_bounds__(kWaveSortThreads) void k_wave_sort(const uint32_t *__restrict__ wkeys, uint32_t nw, uint32_t *__restrict__ order_out)
 {
-    constexpr int kBins = kCoarseMaxLoops + 1;
+    constexpr int kBins = kWaveKeyMax + 1;
     constexpr int kPer = (kBins + kWaveSortThreads - 1) / kWaveSortThreads;     // bins per thread in the scan (3)
     __shared__ uint32_t cnt[kBins];
     __shared__ uint32_t wsum[kWaveSortThreads / 64];
