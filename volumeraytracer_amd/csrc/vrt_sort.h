@@ -331,7 +331,11 @@ constexpr int kCoarseMaxLoops = 2048;
 // Work key of a wavefront: its estimate in half coarse steps (an LDS step counts 2, see VRT_WW_GLOBAL_W), clamped.
 constexpr int kWaveKeyMax = 8192;
 #ifndef VRT_WW_SPREAD_VOX
-#define VRT_WW_SPREAD_VOX 0          // 0 = every coarse step counts the same
+#define VRT_WW_SPREAD_VOX 0          // 0 = every coarse step counts the same (the shipped setting).  Development: count a coarse step
+                                     // VRT_WW_GLOBAL_W / 2 times when the bounding box of the wavefront's 16 representatives outgrows a
+                                     // brick of this many voxels (it will be gathering from global memory then).  Measured with 400 /
+                                     // 640 / 1 000 voxels and weights 2.5 / 2: config 5 12.55 - 13.16 ms against 12.42 - 12.46, config 3
+                                     // 7.07 - 7.16 against 6.90 - 6.93 -- ranking by plain step counts orders better (as in round 2)
 #endif
 #ifndef VRT_WW_GLOBAL_W
 #define VRT_WW_GLOBAL_W 5
