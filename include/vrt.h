@@ -91,6 +91,15 @@ typedef struct vrt_options {
     int32_t  host_lanes;     /* extension: chunks a host-pointer call is cut into per device (pipelined over up to 4 streams so
                               * that uploads and downloads overlap the march), 0 = auto = 1 (measured best: every chunk pays
                               * its own ray ordering and launch tail) */
+    int32_t  fast_math;      /* extension, opt-in, read at trace time: 1 = TOLERANCE MODE.  The default (0) reproduces the reference's
+                              * CPU build bit for bit; with 1 the default slab kernel takes the step length from the hardware
+                              * reciprocal without refinement and rounds the position update half-up in one conversion (8 of the
+                              * step's 79 vector instructions; march -4 % on BASELINE config 3).  Results are then no longer the
+                              * reference's bits: end_iteration equal on > 99.9 % of rays and +-1 otherwise, positions and directions
+                              * within 1e-5 relative on smooth fields (tests/test_gpu_fastmath.py; config 3: 2e-6 at most) -- but a
+                              * ray that grazes a strongly refracting structure amplifies any rounding difference (config 5: 99.9 %
+                              * of the rays within 1e-5, the worst 6e-5 / 2e-4), as the reference's own CUDA and CPU builds differ from
+                              * each other.  Other kernels (direct, 6 KiB, absorption) ignore it. */
 } vrt_options;
 
 #define VRT_KERNEL_AUTO   0

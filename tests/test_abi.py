@@ -35,8 +35,8 @@ def test_abi_version_and_options_layout():
     # struct Options defaults, /root/reference/src/types.h:90
     assert (o.loglevel, o.minimum_gpu, o.write_instance, o.max_cpu) == (0, 0x80, 0, 256)
     assert o.device == -1 and o.kernel == capi.KERNEL_AUTO
-    assert ctypes.sizeof(capi.Options) == 64
-    assert (o.devices, o.host_lanes) == (0, 0)           # extensions default off: one device, auto chunking
+    assert ctypes.sizeof(capi.Options) == 72
+    assert (o.devices, o.host_lanes, o.fast_math) == (0, 0, 0)           # extensions default off: one device, auto chunking
 
 
 def test_band_cut():

@@ -38,7 +38,7 @@ class Options(C.Structure):
     """struct vrt_options == the reference's struct Options (types.h:83-91) + extensions."""
     _fields_ = [("loglevel", C.c_int32), ("minimum_gpu", C.c_uint64), ("write_instance", C.c_int32),
                 ("max_cpu", C.c_uint64), ("device", C.c_int32), ("kernel", C.c_int32),
-                ("sort_rays", C.c_int32), ("slab_lds_bytes", C.c_int32), ("absorption", C.c_int32), ("schedule", C.c_int32), ("devices", C.c_int32), ("host_lanes", C.c_int32)]
+                ("sort_rays", C.c_int32), ("slab_lds_bytes", C.c_int32), ("absorption", C.c_int32), ("schedule", C.c_int32), ("devices", C.c_int32), ("host_lanes", C.c_int32), ("fast_math", C.c_int32)]
 
 
 _lib = None

@@ -450,6 +450,7 @@ int trace_device_impl(vrt_engine *e, Workspace &w, int dir_type, size_t nrays, c
     p.invx = invscale[0]; p.invy = invscale[1]; p.invz = invscale[2];
     step_window(invscale, &p.win_lo, &p.win_span);
     p.field_flags = getenv("VRT_DEBUG_BRICK_TESTS") ? 0u : e->field_flags;   // (tests: force the per-brick prescale test)
+    p.fast_math = o.fast_math ? 1u : 0u;
     for (int d = 0; d < 3; ++d) {                        // upper bound of |g_d * inv_d| per step, rounded up (safe_steps)
         const double g = (double)e->gmax[d] * std::fabs((double)invscale[d]) * (1.0 + 1.0 / 1048576.0);
         float gf = (float)g;
@@ -561,6 +562,7 @@ int trace_device_impl(vrt_engine *e, Workspace &w, int dir_type, size_t nrays, c
                 unsigned long long key = 1469598103934665603ull;
                 auto mix = [&key](unsigned long long v) { key = (key ^ v) * 1099511628211ull; };
                 mix(nrays); mix(iterations); mix((unsigned long long)dir_type); mix(geo.seg_bytes); mix((unsigned long long)o.sort_rays);
+                mix((unsigned long long)p.fast_math);
                 for (int d = 0; d < 3; ++d) { uint32_t b; memcpy(&b, &invscale[d], 4); mix(b); }
                 if (t.key != key) { t.key = key; t.state = 0; t.choice = 2; }
                 if (t.state < 4) {
@@ -1082,6 +1084,7 @@ void vrt_options_default(vrt_options *opt)
     opt->sort_rays = 0;
     opt->devices = 0;
     opt->host_lanes = 0;
+    opt->fast_math = 0;
 }
 
 int vrt_abi_version(void) { return VRT_ABI_VERSION; }

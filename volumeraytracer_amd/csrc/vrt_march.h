@@ -53,6 +53,7 @@ struct MarchParams {
     uint32_t out_pos_bias;    // added to end_pos / path on output: 0 at the seam, 0x10000 for the scene
                               // layer's "+0x10000" epilogue (image_util.cpp:770-771)
     unsigned long long *clock_out; // optional: 4 words {s_memtime, s_memrealtime} x {begin, end} of one wavefront (wave 0 of block 0)
+    uint32_t fast_math;       // opt-in tolerance mode (vrt_options.fast_math): the 10 KiB slab kernel takes the FAST step (below)
     uint32_t field_flags;     // kFieldPrescaleOk: every voxel of the field passes prescale_ok (vrt_slab.h), bricks need no test
     float gstep_norm;         // slab kernel: upper bound of the LENGTH of the change of dir in one step (longest gradient vector x max |inv_d|)
     float gstep[3];           // slab kernel: upper bound of |g_d * inv_d|, the change of dir_d in one step (.cu:344-345):
@@ -114,6 +115,19 @@ __device__ __forceinline__ uint32_t add_round(uint32_t pos, float s)
     return t - sg;
 }
 
+// Opt-in tolerance mode (vrt_options.fast_math; north_star allows 1e-5 relative): inside the step window the step length comes
+// from v_rcp_f32 alone (1 ulp, no refinement: -2 instructions) and the position update is pos + floor(s + 1/2) in one
+// conversion (v_cvt_rpi_i32_f32 on the signed value: it differs from the reference's round-half-away only on exact negative
+// ties; -2 instructions per component).  8 of the proven step's 79 vector instructions.  The interpolation itself is NOT
+// touched: fma(a, wl, b * wr) and fma(t, b - a, a) are two instructions each, there is nothing to save there.
+__device__ __forceinline__ float ilen_fast(float d) { return 0x42000000p0f * __builtin_amdgcn_rcpf(d); }
+__device__ __forceinline__ uint32_t add_round_fast(uint32_t pos, float s)
+{
+    uint32_t m;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(m) : "v"(s));
+    return pos + m;
+}
+
 // ---- voxel pair loads: voxel z and z+1 at one (x,y), as 2 x f4 --------------------------
 
 typedef float   vox_f32 __attribute__((ext_vector_type(4)));   // 16 B: {dx, dy, dz, w}
@@ -150,7 +164,7 @@ struct Ray {
 // whole brick from a ballot taken while staging it), so the opacity test cannot fire and is skipped.
 // PRESCALED: the x, y, z channels of the corners already carry the interpolation's factor 2^-48 (the slab kernel
 // scales them once while staging a brick, exactly -- see stage_scale_ok in vrt_slab.h); the w channel is always raw.
-template <bool PRESCALED = false>
+template <bool PRESCALED = false, bool FAST = false>
 __device__ __forceinline__ bool march_step(Ray &r, const f4 (&c)[8], float invx, float invy, float invz,
                                            StepWindow win, bool check_w = true)
 {
@@ -205,6 +219,13 @@ __device__ __forceinline__ bool march_step(Ray &r, const f4 (&c)[8], float invx,
         r.pz += (uint32_t)round_to_i32((r.dz * invz) * ilen);
         return false;
     }
+    if constexpr (FAST) {
+        const float ilen = ilen_fast(dot);
+        r.px = add_round_fast(r.px, (r.dx * invx) * ilen);
+        r.py = add_round_fast(r.py, (r.dy * invy) * ilen);
+        r.pz = add_round_fast(r.pz, (r.dz * invz) * ilen);
+        return false;
+    }
     const float ilen = ilen_short(dot);                     // == 0x42000000p0f / dot, proven exhaustively
     r.px = add_round(r.px, (r.dx * invx) * ilen);           // |s| < 2^30 inside the window (StepWindow, condition 2)
     r.py = add_round(r.py, (r.dy * invy) * ilen);
@@ -229,7 +250,7 @@ __device__ __forceinline__ Weights lerp_weights(const Ray &r)
 // (safe_steps, vrt_slab.h), so the step carries no test at all.
 // UNIT_INV = true: invscale is exactly (1, 1, 1) (every BASELINE config): fma(g, 1, d) == g + d and d * 1 == d bit for bit,
 // so the three products with invscale are not computed.
-template <bool PRESCALED, bool WINDOW_TEST, bool UNIT_INV = false>
+template <bool PRESCALED, bool WINDOW_TEST, bool UNIT_INV = false, bool FAST = false>
 __device__ __forceinline__ void march_step_now(Ray &r, const f4 (&c)[8], const Weights &w, float invx, float invy, float invz, StepWindow win)
 {
     const float wrx = w.wrx, wlx = w.wlx, wry = w.wry, wly = w.wly, wrz = w.wrz, wlz = w.wlz;
@@ -249,8 +270,10 @@ __device__ __forceinline__ void march_step_now(Ray &r, const f4 (&c)[8], const W
     else { r.dx = fma_(g[0], invx, r.dx); r.dy = fma_(g[1], invy, r.dy); r.dz = fma_(g[2], invz, r.dz); }
     const float dot = fma_(r.dz, r.dz, fma_(r.dx, r.dx, r.dy * r.dy));
     const float ex = UNIT_INV ? r.dx : r.dx * invx, ey = UNIT_INV ? r.dy : r.dy * invy, ez = UNIT_INV ? r.dz : r.dz * invz;
-    const float ilen = ilen_short(dot);                     // garbage outside the window, replaced below
-    uint32_t nx = add_round(r.px, ex * ilen), ny = add_round(r.py, ey * ilen), nz = add_round(r.pz, ez * ilen);
+    const float ilen = FAST ? ilen_fast(dot) : ilen_short(dot);                     // garbage outside the window, replaced below
+    uint32_t nx, ny, nz;
+    if constexpr (FAST) { nx = add_round_fast(r.px, ex * ilen); ny = add_round_fast(r.py, ey * ilen); nz = add_round_fast(r.pz, ez * ilen); }
+    else                { nx = add_round(r.px, ex * ilen); ny = add_round(r.py, ey * ilen); nz = add_round(r.pz, ez * ilen); }
     const bool outside = WINDOW_TEST && !((__float_as_uint(dot) - win.lo) < win.span);
     if (outside) {                                          // rare: skipped by one scalar branch when no lane needs it
         const float il = 0x42000000p0f / dot;

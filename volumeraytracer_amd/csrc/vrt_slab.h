@@ -464,7 +464,8 @@ __device__ __forceinline__ void gather_lds_at(uint32_t a0, uint32_t sy16, uint32
 // SCHED: 0 static (one wavefront per group of 64 slots), 1 persistent (wavefronts draw whole groups from a counter),
 // 2 persistent and time-sliced (wavefronts draw (slice, group) tickets: a group marches slice_steps wave-steps, parks its
 // ray state in global memory and is resumed later by whichever wavefront draws its next ticket).
-template <typename FieldT, typename DirT, int VPL, int OCC, bool ABSORB, int SCHED = 0>
+// FAST: the opt-in tolerance step (vrt_march.h, ilen_fast / add_round_fast) in every loop; instantiated for the default geometry only.
+template <typename FieldT, typename DirT, int VPL, int OCC, bool ABSORB, int SCHED = 0, bool FAST = false>
 __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(const MarchParams p)
 {
     constexpr bool PERSIST = SCHED != 0;
@@ -781,11 +782,11 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                                 have_xy = xy;
                                 have_z = z;
                             }
-                            if (march_step(r, keptf, invx, invy, invz, win)) { rem_w = it; it = 0; } else --it;
+                            if (march_step<false, FAST>(r, keptf, invx, invy, invz, win)) { rem_w = it; it = 0; } else --it;
                         } else {
                             f4 c[8];
                             gather_global<FieldT>(f, r, p.By, p.Bz, c);
-                            if (march_step(r, c, invx, invy, invz, win)) { rem_w = it; it = 0; } else --it;
+                            if (march_step<false, FAST>(r, c, invx, invy, invz, win)) { rem_w = it; it = 0; } else --it;
                         }
                     }
                 }
@@ -867,7 +868,7 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                                     f4 c[8];
 #pragma unroll
                                     for (int q = 0; q < 8; ++q) cvt_vox(v[q], c[q]);
-                                    march_step_now<kPrescaled, decltype(window_test)::value, decltype(unit_inv)::value>(r, c, w, invx, invy, invz, win);
+                                    march_step_now<kPrescaled, decltype(window_test)::value, decltype(unit_inv)::value, FAST>(r, c, w, invx, invy, invz, win);
                                 }
                             };
 #ifdef VRT_SLAB_NO_UNIT_INV
@@ -917,9 +918,9 @@ __global__ __launch_bounds__(64 * kSlabWavesPerBlock, OCC) void k_march_slab(con
                             f4 c[8];
                             gather_lds_at<lvox>(mad_hi16(r.pz, (uint32_t)sizeof(lvox), mad_hi16(r.py, sy16, mad_hi16(r.px, sx16, seg_addr))), sy16, sx16, c);
                             if constexpr (kHasW) {
-                                if (march_step<kPrescaled>(r, c, invx, invy, invz, win, true)) { rem_w = it; it = 0; } else --it;
+                                if (march_step<kPrescaled, FAST>(r, c, invx, invy, invz, win, true)) { rem_w = it; it = 0; } else --it;
                             } else {
-                                (void)march_step<kPrescaled>(r, c, invx, invy, invz, win, false);
+                                (void)march_step<kPrescaled, FAST>(r, c, invx, invy, invz, win, false);
                                 --it;
                             }
                         }
@@ -1191,7 +1192,7 @@ inline SlabGeometry slab_geometry(uint32_t want, uint32_t nrays, uint32_t Bx, ui
     return {16384, 2, all};
 }
 
-template <typename FieldT, typename DirT, int BYTES, int OCC, bool ABSORB, bool COMPLETE>
+template <typename FieldT, typename DirT, int BYTES, int OCC, bool ABSORB, bool COMPLETE, bool FAST = false>
 hipError_t launch_slab_bytes(const MarchParams &p, int num_cu, hipStream_t s)
 {
     constexpr int VPL = BYTES / (64 * (int)sizeof(typename LdsVox<FieldT>::type));
@@ -1203,13 +1204,13 @@ hipError_t launch_slab_bytes(const MarchParams &p, int num_cu, hipStream_t s)
         const unsigned resident = (unsigned)(num_cu > 0 ? num_cu : 256) * (unsigned)OCC;
         const unsigned grid = groups_blocks < resident ? groups_blocks : resident;
         if constexpr (!ABSORB) if (p.park) {
-            k_march_slab<FieldT, DirT, VPL, OCC, ABSORB, 2><<<grid, threads, lds, s>>>(p);
+            k_march_slab<FieldT, DirT, VPL, OCC, ABSORB, 2, FAST><<<grid, threads, lds, s>>>(p);
             return hipGetLastError();
         }
-        k_march_slab<FieldT, DirT, VPL, OCC, ABSORB, 1><<<grid, threads, lds, s>>>(p);
+        k_march_slab<FieldT, DirT, VPL, OCC, ABSORB, 1, FAST><<<grid, threads, lds, s>>>(p);
         return hipGetLastError();
     }
-    k_march_slab<FieldT, DirT, VPL, OCC, ABSORB, 0><<<groups_blocks, threads, lds, s>>>(p);
+    k_march_slab<FieldT, DirT, VPL, OCC, ABSORB, 0, FAST><<<groups_blocks, threads, lds, s>>>(p);
     return hipGetLastError();
 }
 
@@ -1225,6 +1226,8 @@ hipError_t launch_slab(const MarchParams &p, SlabGeometry g, int num_cu, hipStre
         if (g.seg_bytes <= 6144) return launch_slab_bytes<FieldT, DirT, 6144, 6, true, true>(p, num_cu, s);
         return launch_slab_bytes<FieldT, DirT, 10240, 4, true, true>(p, num_cu, s);
     }
+    // opt-in tolerance mode: the default geometry has a FAST instantiation; every other kernel computes exactly
+    if (p.fast_math && g.seg_bytes == 10240) return launch_slab_bytes<FieldT, DirT, 10240, 4, false, true, true>(p, num_cu, s);
     switch (g.seg_bytes) {
     case 6144:  return launch_slab_bytes<FieldT, DirT, 6144, 6, false, true>(p, num_cu, s);
     case 8192:  return launch_slab_bytes<FieldT, DirT, 8192, 5, false, kAll>(p, num_cu, s);
