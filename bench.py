@@ -542,6 +542,8 @@ def main():
                 "note": "vrt_options.fast_math = 1 (tolerance mode); compared with this run's exact results on all rays (errors relative to the "
                         "field extent / the largest direction); a ray that grazes a strongly refracting structure amplifies any rounding "
                         "difference, so the maximum can exceed 1e-5 while rays_within_1e-5 says how many stay inside; NOT the headline"}
+        if fast["end_iteration_equal_share"] == 1.0 and fast["position_max_rel_err"] == 0.0 and fast["direction_max_rel_err"] == 0.0:
+            fast["ignored"] = True      # the kernel this workload selects (6 KiB segments for dense ray sets, direct) has no tolerance variant
         del exact_rec
     # a scheduler failure (a bounded wait of the time-sliced schedule that ran out) would have left rays unfinished:
     # vrt_trace_status reports it for every device-pointer call issued so far
