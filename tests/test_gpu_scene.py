@@ -178,3 +178,4 @@ def test_scene_build_field_bits(monkeypatch, kind, dims):
     for mode in fields:
         assert np.array_equal(fields[mode].reshape(-1).view(np.uint8), np.asarray(want).reshape(-1).view(np.uint8)), mode
     assert np.array_equal(scans["tiled"][0].view(np.uint32), scans["pervoxel"][0].view(np.uint32)) and scans["tiled"][1] == scans["pervoxel"][1]
+
