@@ -269,7 +269,11 @@ __global__ __launch_bounds__(kTY * kTZ) void k_scene_build_tiled(const LogSrc lg
                 o.w = (float)((int32_t)(0x7FFFFFFFu - tr) / 0x10000);                         // cuda_volume_raytracer.cu:656-659
                 a[0] = o.x; a[1] = o.y; a[2] = o.z;
             } else {
-                uint32_t sum[3] = {0u, 0u, 0u};                                               // int32 arithmetic wraps in the reference binary
+                uint32_t sum[3];                                                              // int32 arithmetic wraps in the reference binary
+                // Two forms of the same wrapping sums, chosen by measurement (MI355X): the per-term form is faster for array
+                // sources (512^3: 0.57 vs 0.62 ms), the regrouped one for LUT sources (1024^3: 4.95 vs 5.42 ms).
+                if constexpr (!LogSrc::kLut) {
+                sum[0] = sum[1] = sum[2] = 0u;
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -281,6 +285,26 @@ __global__ __launch_bounds__(kTY * kTZ) void k_scene_build_tiled(const LogSrc lg
                             if (j != 1) sum[1] += (uint32_t)((j - 1) * stamp_m(i, k)) * v;
                             if (k != 1) sum[2] += (uint32_t)((k - 1) * stamp_m(i, j)) * v;
                         }
+                } else {
+                // The sums wrap (two's complement), so they form a ring and may be regrouped freely: per axis, 14 x (the four
+                // corner differences of the two outer planes) + 47 x (the four edge differences) + 162 x (the centre difference)
+                // -- 9 integer multiplications instead of 54 (32-bit integer multiplies issue at a quarter of the rate)
+                auto m3 = [](uint32_t c00, uint32_t c01, uint32_t c02, uint32_t c10, uint32_t c11, uint32_t c12, uint32_t c20,
+                             uint32_t c21, uint32_t c22) {
+                    return 14u * (c00 + c02 + c20 + c22) + 47u * (c01 + c10 + c12 + c21) + 162u * c11;
+                };
+#define VRT_PL(i) p[(P + 1 + (i)) % 3]
+#define VRT_DX(j, k) (VRT_PL(2)[j][k] - VRT_PL(0)[j][k])
+#define VRT_DY(i, k) (VRT_PL(i)[2][k] - VRT_PL(i)[0][k])
+#define VRT_DZ(i, j) (VRT_PL(i)[j][2] - VRT_PL(i)[j][0])
+                sum[0] = m3(VRT_DX(0, 0), VRT_DX(0, 1), VRT_DX(0, 2), VRT_DX(1, 0), VRT_DX(1, 1), VRT_DX(1, 2), VRT_DX(2, 0), VRT_DX(2, 1), VRT_DX(2, 2));
+                sum[1] = m3(VRT_DY(0, 0), VRT_DY(0, 1), VRT_DY(0, 2), VRT_DY(1, 0), VRT_DY(1, 1), VRT_DY(1, 2), VRT_DY(2, 0), VRT_DY(2, 1), VRT_DY(2, 2));
+                sum[2] = m3(VRT_DZ(0, 0), VRT_DZ(0, 1), VRT_DZ(0, 2), VRT_DZ(1, 0), VRT_DZ(1, 1), VRT_DZ(1, 2), VRT_DZ(2, 0), VRT_DZ(2, 1), VRT_DZ(2, 2));
+#undef VRT_PL
+#undef VRT_DX
+#undef VRT_DY
+#undef VRT_DZ
+                }
                 const int32_t weight = 812 * 0x100;
                 int16_t q16[3];
 #pragma unroll
