@@ -197,10 +197,13 @@ __global__ __launch_bounds__(kTY * kTZ) void k_scene_build_tiled(const LogSrc lg
     // global loads are issued a plane ahead (gload at the top of an iteration) and consumed at its bottom (lstore) or in the
     // next iteration (the translucency of the output voxel): their latency lies under the arithmetic of the current plane.
     // (Four planes ahead, with the loop unrolled by four, was measured too: 0.83 / 0.66 / 5.79 ms against 0.79 / 0.63 / 5.81
-    // for 512^3 float / 512^3 fixed-point / 1024^3 LUT -- all three builds produce about 2 x 10^11 voxels per second
-    // whatever their bytes per voxel: the kernel is bound by its instructions per voxel (54 multiply-adds, three IEEE
-    // divisions, nine LDS reads, the register rotation), not by memory.  Regrouping the fixed-point sums -- they wrap, so
-    // they form a ring -- into 9 multiplications instead of 54 changed nothing either.)
+    // for 512^3 float / 512^3 fixed-point / 1024^3 LUT at the time: no gain.  The compiler guards these conditional loads with
+    // vmcnt(0) -- it cannot count operations in flight across the branches -- so a wavefront waits for the plane it has just
+    // requested (SQ_WAIT_ANY = 69 % of the wave-cycles of the 1024^3 LUT build); with every load and LDS write made unconditional
+    // (clamped addresses, dummy slots) the waits become vmcnt(3) / (2) / (1) and the time does not move -- 4.36-4.72 against 4.35-4.66,
+    // one or two planes ahead alike: eight wavefronts per SIMD already cover the wait.  Dealing the tiles of an 8-bit volume
+    // to the XCDs in quads of z-neighbours, so that the four tiles sharing a 128-byte line share an L2, cuts the fetched bytes
+    // from 2.85 to 1.08 GB and makes the build slower, 5.0-5.2 ms.  Both kept as a patch: tools/r03_batches/scene_unconditional_loads.patch.)
     typename LogSrc::raw_t stage[2] = {};
     auto gload = [&](uint32_t xin) {
 #pragma unroll
@@ -224,6 +227,12 @@ __global__ __launch_bounds__(kTY * kTZ) void k_scene_build_tiled(const LogSrc lg
 #else
     constexpr bool kRotate = kFloat;
 #endif
+#ifdef VRT_SCENE_NO_PARTIALS
+    constexpr bool kPartials = false;
+#else
+    constexpr bool kPartials = !kFloat;
+#endif
+    uint32_t part[3][5] = {};
     T p[3][3][3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -238,13 +247,35 @@ __global__ __launch_bounds__(kTY * kTZ) void k_scene_build_tiled(const LogSrc lg
         constexpr int P = decltype(ph)::value;            // (kRotate: always 2, and plane t - 2 + i is in set i)
         if (t + 1 < nplanes) gload(x0 + t + 1);           // in flight during the arithmetic below
         if (active && t >= 1 && t - 1 < nx) tr_next = transl.raw((size_t)(x0 + t) * Ny * Nz + tr_off);   // of output plane x0 + t - 1, needed next iteration
+        if constexpr (kPartials) {
+            // Fixed-point family: the sums wrap (two's complement), so they form a ring and may be regrouped freely.  Each plane
+            // contributes to the three sums of its three output planes only through five numbers, computed once when it arrives:
+            // its stamp-weighted 2-D sum (x derivative = that of the plane ahead - that of the plane behind) and, for y and z,
+            // the outer pair and the centre of its three differences across the rows / the columns (weighted 14 | 47 or 47 | 162
+            // by the plane's position).  36 integer operations per voxel instead of 108, 15 live registers instead of 27
+            // (56 VGPRs, 8 wavefronts per SIMD).  Measured against the term-by-term form (-DVRT_SCENE_NO_PARTIALS): 1024^3 LUT
+            // 4.81-4.96 -> 4.35-4.66 ms; 512^3 from arrays unchanged within the noise (0.54-0.57 vs 0.58-0.63: that build moves
+            // 16 B per voxel and sits at the memory rate).  (Regrouping inside the voxel only -- 9 multiplications instead of 54,
+            // every plane still differenced three times -- was the earlier form for LUT scenes: 4.95 ms.)
+            uint32_t c[3][3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+            for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                if constexpr (kRotate) { p[0][j][k] = p[1][j][k]; p[1][j][k] = p[2][j][k]; }
-                p[P][j][k] = plane[t & 1u][ty + j][tz + k];
-            }
+                for (int k = 0; k < 3; ++k) c[j][k] = plane[t & 1u][ty + j][tz + k];
+            part[P][0] = 14u * (c[0][0] + c[0][2] + c[2][0] + c[2][2]) + 47u * (c[0][1] + c[1][0] + c[1][2] + c[2][1]) + 162u * c[1][1];
+            part[P][1] = (c[2][0] - c[0][0]) + (c[2][2] - c[0][2]);      // y differences, outer columns
+            part[P][2] = c[2][1] - c[0][1];                              //                centre column
+            part[P][3] = (c[0][2] - c[0][0]) + (c[2][2] - c[2][0]);      // z differences, outer rows
+            part[P][4] = c[1][2] - c[1][0];                              //                centre row
+        } else {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    if constexpr (kRotate) { p[0][j][k] = p[1][j][k]; p[1][j][k] = p[2][j][k]; }
+                    p[P][j][k] = plane[t & 1u][ty + j][tz + k];
+                }
+        }
         if (t >= 2 && active) {
             const uint32_t x = x0 + t - 2;
             const size_t idx = ((size_t)x * Oy + y) * Oz + z;
@@ -270,40 +301,24 @@ __global__ __launch_bounds__(kTY * kTZ) void k_scene_build_tiled(const LogSrc lg
                 a[0] = o.x; a[1] = o.y; a[2] = o.z;
             } else {
                 uint32_t sum[3];                                                              // int32 arithmetic wraps in the reference binary
-                // Two forms of the same wrapping sums, chosen by measurement (MI355X): the per-term form is faster for array
-                // sources (512^3: 0.57 vs 0.62 ms), the regrouped one for LUT sources (1024^3: 4.95 vs 5.42 ms).
-                if constexpr (!LogSrc::kLut) {
-                sum[0] = sum[1] = sum[2] = 0u;
+                if constexpr (kPartials) {
+                    const uint32_t *pa = part[(P + 1) % 3], *pb = part[(P + 2) % 3], *pc = part[P];   // planes x, x + 1, x + 2
+                    sum[0] = pc[0] - pa[0];
+                    sum[1] = 14u * (pa[1] + pc[1]) + 47u * (pa[2] + pc[2] + pb[1]) + 162u * pb[2];
+                    sum[2] = 14u * (pa[3] + pc[3]) + 47u * (pa[4] + pc[4] + pb[3]) + 162u * pb[4];
+                } else {                                                                      // term by term, as k_scene_build
+                    sum[0] = sum[1] = sum[2] = 0u;
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
+                    for (int i = 0; i < 3; ++i)
 #pragma unroll
-                    for (int j = 0; j < 3; ++j)
+                        for (int j = 0; j < 3; ++j)
 #pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            const uint32_t v = p[(P + 1 + i) % 3][j][k];
-                            if (i != 1) sum[0] += (uint32_t)((i - 1) * stamp_m(j, k)) * v;
-                            if (j != 1) sum[1] += (uint32_t)((j - 1) * stamp_m(i, k)) * v;
-                            if (k != 1) sum[2] += (uint32_t)((k - 1) * stamp_m(i, j)) * v;
-                        }
-                } else {
-                // The sums wrap (two's complement), so they form a ring and may be regrouped freely: per axis, 14 x (the four
-                // corner differences of the two outer planes) + 47 x (the four edge differences) + 162 x (the centre difference)
-                // -- 9 integer multiplications instead of 54 (32-bit integer multiplies issue at a quarter of the rate)
-                auto m3 = [](uint32_t c00, uint32_t c01, uint32_t c02, uint32_t c10, uint32_t c11, uint32_t c12, uint32_t c20,
-                             uint32_t c21, uint32_t c22) {
-                    return 14u * (c00 + c02 + c20 + c22) + 47u * (c01 + c10 + c12 + c21) + 162u * c11;
-                };
-#define VRT_PL(i) p[(P + 1 + (i)) % 3]
-#define VRT_DX(j, k) (VRT_PL(2)[j][k] - VRT_PL(0)[j][k])
-#define VRT_DY(i, k) (VRT_PL(i)[2][k] - VRT_PL(i)[0][k])
-#define VRT_DZ(i, j) (VRT_PL(i)[j][2] - VRT_PL(i)[j][0])
-                sum[0] = m3(VRT_DX(0, 0), VRT_DX(0, 1), VRT_DX(0, 2), VRT_DX(1, 0), VRT_DX(1, 1), VRT_DX(1, 2), VRT_DX(2, 0), VRT_DX(2, 1), VRT_DX(2, 2));
-                sum[1] = m3(VRT_DY(0, 0), VRT_DY(0, 1), VRT_DY(0, 2), VRT_DY(1, 0), VRT_DY(1, 1), VRT_DY(1, 2), VRT_DY(2, 0), VRT_DY(2, 1), VRT_DY(2, 2));
-                sum[2] = m3(VRT_DZ(0, 0), VRT_DZ(0, 1), VRT_DZ(0, 2), VRT_DZ(1, 0), VRT_DZ(1, 1), VRT_DZ(1, 2), VRT_DZ(2, 0), VRT_DZ(2, 1), VRT_DZ(2, 2));
-#undef VRT_PL
-#undef VRT_DX
-#undef VRT_DY
-#undef VRT_DZ
+                            for (int k = 0; k < 3; ++k) {
+                                const uint32_t v = p[(P + 1 + i) % 3][j][k];
+                                if (i != 1) sum[0] += (uint32_t)((i - 1) * stamp_m(j, k)) * v;
+                                if (j != 1) sum[1] += (uint32_t)((j - 1) * stamp_m(i, k)) * v;
+                                if (k != 1) sum[2] += (uint32_t)((k - 1) * stamp_m(i, j)) * v;
+                            }
                 }
                 const int32_t weight = 812 * 0x100;
                 int16_t q16[3];
