@@ -1302,7 +1302,13 @@ static int scene_create_impl(vrt_scene_handle *out, int dim, const size_t *bound
     // (one thread per voxel, 27 global loads) for A/B runs and for the test that holds the two to the same bits
     bool tiled = true;
     if (const char *ev = getenv("VRT_SCENE_BUILD")) tiled = strcmp(ev, "pervoxel") != 0;
-    const dim3 tgrid((sc->N[2] - 2 + vrt::kTZ - 1) / vrt::kTZ, (sc->N[1] - 2 + vrt::kTY - 1) / vrt::kTY, (sc->N[0] - 2 + vrt::kXS - 1) / vrt::kXS);
+    // runs aligned to four voxels of the field's linear index (k_scene_build_tiled): possible when the shift of a row is the same in every plane
+    uint32_t zshift = 0;
+    {
+        const unsigned long long oy = sc->N[1] - 2, oz = sc->N[2] - 2;
+        if ((oy * oz) % 4ull == 0 && oz % 4ull != 0 && !(getenv("VRT_SCENE_ZSHIFT") && atoi(getenv("VRT_SCENE_ZSHIFT")) == 0)) zshift = vrt::kZS;
+    }
+    const dim3 tgrid((sc->N[2] - 2 + zshift + vrt::kTZ - 1) / vrt::kTZ, (sc->N[1] - 2 + vrt::kTY - 1) / vrt::kTY, (sc->N[0] - 2 + vrt::kXS - 1) / vrt::kXS);
     const size_t nwg = (size_t)tgrid.x * tgrid.y * tgrid.z;
     const unsigned grid = (unsigned)((fvox + 255) / 256);
     void *d_part = nullptr;
@@ -1312,7 +1318,7 @@ static int scene_create_impl(vrt_scene_handle *out, int dim, const size_t *bound
     Range range("vrt: scene build");
 #define VRT_BUILD(LOGSRC, TRSRC, VOX)                                                                                        \
     do {                                                                                                                     \
-        if (tiled) vrt::k_scene_build_tiled<<<tgrid, vrt::kTY * vrt::kTZ, 0, s>>>(LOGSRC, TRSRC, sc->N[0], sc->N[1], sc->N[2], (VOX *)e->field, derr, d_tc, part); \
+        if (tiled) vrt::k_scene_build_tiled<<<tgrid, vrt::kTY * vrt::kTZ, 0, s>>>(LOGSRC, TRSRC, sc->N[0], sc->N[1], sc->N[2], (VOX *)e->field, derr, d_tc, part, zshift); \
         else       vrt::k_scene_build<<<grid, 256, 0, s>>>(LOGSRC, TRSRC, sc->N[0], sc->N[1], sc->N[2], (VOX *)e->field, derr, d_tc);          \
     } while (0)
     if (ior_type == VRT_F32) {

@@ -160,16 +160,18 @@ __global__ __launch_bounds__(256) void k_scene_build(const LogSrc lg, const TrSr
 // squared gradient length, smallest non-zero magnitude) is fused in: each workgroup reduces its voxels and writes five
 // words; k_absmax_reduce folds them.  (Atomics on five addresses from 16 384 workgroups would serialise, see k_ray_bounds.)
 constexpr int kTY = 8, kTZ = 32, kXS = 32;              // output tile of a workgroup: kXS x kTY x kTZ voxels (x walked)
+constexpr int kZS = 3;                                  // largest row shift (voxels) of a tile: runs aligned to four voxels
 
 template <typename LogSrc, typename TrSrc, typename VoxT>
 __global__ __launch_bounds__(kTY * kTZ) void k_scene_build_tiled(const LogSrc lg, const TrSrc transl, uint32_t Nx, uint32_t Ny, uint32_t Nz,
                                                                   VoxT *__restrict__ field, SceneErr *err,
                                                                   uint32_t *__restrict__ transl_cropped /* or nullptr */,
-                                                                  uint32_t *__restrict__ absmax_partial /* [workgroups][5] */)
+                                                                  uint32_t *__restrict__ absmax_partial /* [workgroups][5] */,
+                                                                  uint32_t zshift /* 0 or kZS: see below */)
 {
     constexpr bool kFloat = sizeof(VoxT) == 16;
     using T = std::conditional_t<kFloat, float, uint32_t>;   // log values: float, or int32 held as uint32 (the sums wrap)
-    constexpr int PY = kTY + 2, PZ = kTZ + 2, kThreads = kTY * kTZ;
+    constexpr int PY = kTY + 2, PZ = kTZ + 2 + kZS, kThreads = kTY * kTZ;
     __shared__ T plane[2][PY][PZ];
     __shared__ uint32_t tab_lg[LogSrc::kLut ? 256 : 1], tab_tr[TrSrc::kLut ? 256 : 1];   // LUT scenes: the two tables, one look-up per staged voxel
     if constexpr (LogSrc::kLut) { for (uint32_t k = threadIdx.x; k < 256u; k += kThreads) tab_lg[k] = lg.table_bits(k); }
@@ -177,8 +179,17 @@ __global__ __launch_bounds__(kTY * kTZ) void k_scene_build_tiled(const LogSrc lg
     const uint32_t Ox = Nx - 2, Oy = Ny - 2, Oz = Nz - 2;
     const uint32_t tid = threadIdx.x, tz = tid % kTZ, ty = tid / kTZ;
     const uint32_t z0 = blockIdx.x * kTZ, y0 = blockIdx.y * kTY, x0 = blockIdx.z * kXS;
-    const uint32_t y = y0 + ty, z = z0 + tz;
+    // Row shift: the field is dense, its rows of Oz voxels are in general not a multiple of a memory sector long, so a run of
+    // kTZ voxels starting at a multiple of kTZ straddles sectors it shares with the neighbouring workgroup's run (measured:
+    // 3.7 -> 4.0 TB/s for int16 voxels when the rows are 32-byte aligned, 4.1 -> 4.4 for float voxels at 64 bytes).
+    // With zshift = kZS = 3 the runs of row y start at z = kTZ * i - ((y * Oz) & 3), i.e. at a multiple of four voxels of the
+    // field's linear index -- the same shift in every plane, because the engine only asks for it when Oy * Oz is a multiple of
+    // four; the LDS tile is kZS columns wider for it.
+    const uint32_t y = y0 + ty, zsh = (y * Oz) & zshift;
+    const uint32_t z = z0 + tz - zsh;                     // wraps below zero for the first lanes of a shifted row's first run: idle
     const bool active = y < Oy && z < Oz;
+    const uint32_t zcol = tz + zshift - zsh;              // this thread's first column of the tile (the tile starts at z0 - zshift)
+    const uint32_t pw = (uint32_t)kTZ + 2u + zshift;      // staged columns
     const uint32_t nx = Ox - x0 < (uint32_t)kXS ? Ox - x0 : (uint32_t)kXS;     // output planes of this workgroup
     const uint32_t nplanes = nx + 2;
 
@@ -189,10 +200,11 @@ __global__ __launch_bounds__(kTY * kTZ) void k_scene_build_tiled(const LogSrc lg
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const uint32_t sidx = tid + kThreads * q;
-        s_ly[q] = sidx / PZ;
-        s_lz[q] = sidx - s_ly[q] * PZ;
-        s_ok[q] = sidx < (uint32_t)(PY * PZ) && y0 + s_ly[q] < Ny && z0 + s_lz[q] < Nz;
-        s_off[q] = (size_t)(y0 + s_ly[q]) * Nz + (z0 + s_lz[q]);
+        s_ly[q] = sidx / pw;
+        s_lz[q] = sidx - s_ly[q] * pw;
+        const uint32_t zin = z0 + s_lz[q] - zshift;       // wraps below zero left of the volume
+        s_ok[q] = sidx < (uint32_t)PY * pw && y0 + s_ly[q] < Ny && zin < Nz;
+        s_off[q] = (size_t)(y0 + s_ly[q]) * Nz + zin;
     }
     // global loads are issued a plane ahead (gload at the top of an iteration) and consumed at its bottom (lstore) or in the
     // next iteration (the translucency of the output voxel): their latency lies under the arithmetic of the current plane.
@@ -203,7 +215,7 @@ __global__ __launch_bounds__(kTY * kTZ) void k_scene_build_tiled(const LogSrc lg
     // (clamped addresses, dummy slots) the waits become vmcnt(3) / (2) / (1) and the time does not move -- 4.36-4.72 against 4.35-4.66,
     // one or two planes ahead alike: eight wavefronts per SIMD already cover the wait.  Dealing the tiles of an 8-bit volume
     // to the XCDs in quads of z-neighbours, so that the four tiles sharing a 128-byte line share an L2, cuts the fetched bytes
-    // from 2.85 to 1.08 GB and makes the build slower, 5.0-5.2 ms.  Both kept as a patch: tools/r03_batches/scene_unconditional_loads.patch.)
+    // (raw FETCH_SIZE) from 2.85 to 1.08 GB and makes the build slower, 5.0-5.2 ms.  Both kept as a patch: tools/r03_batches/scene_unconditional_loads.patch.)
     typename LogSrc::raw_t stage[2] = {};
     auto gload = [&](uint32_t xin) {
 #pragma unroll
@@ -261,7 +273,7 @@ __global__ __launch_bounds__(kTY * kTZ) void k_scene_build_tiled(const LogSrc lg
 #pragma unroll
             for (int j = 0; j < 3; ++j)
 #pragma unroll
-                for (int k = 0; k < 3; ++k) c[j][k] = plane[t & 1u][ty + j][tz + k];
+                for (int k = 0; k < 3; ++k) c[j][k] = plane[t & 1u][ty + j][zcol + k];
             part[P][0] = 14u * (c[0][0] + c[0][2] + c[2][0] + c[2][2]) + 47u * (c[0][1] + c[1][0] + c[1][2] + c[2][1]) + 162u * c[1][1];
             part[P][1] = (c[2][0] - c[0][0]) + (c[2][2] - c[0][2]);      // y differences, outer columns
             part[P][2] = c[2][1] - c[0][1];                              //                centre column
@@ -273,7 +285,7 @@ __global__ __launch_bounds__(kTY * kTZ) void k_scene_build_tiled(const LogSrc lg
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     if constexpr (kRotate) { p[0][j][k] = p[1][j][k]; p[1][j][k] = p[2][j][k]; }
-                    p[P][j][k] = plane[t & 1u][ty + j][tz + k];
+                    p[P][j][k] = plane[t & 1u][ty + j][zcol + k];
                 }
         }
         if (t >= 2 && active) {
