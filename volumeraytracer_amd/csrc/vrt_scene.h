@@ -146,11 +146,17 @@ __global__ __launch_bounds__(256) void k_scene_build(const LogSrc lg, const TrSr
 // byte loads + table look-ups for a LUT scene) kept it at 0.37 of the HBM peak at 512^3 and 0.12 at 1024^3 + LUT
 // (profiles/r02_scene_build_512.txt).  Here a workgroup owns a column of kTY x kTZ output voxels and walks it along x
 // (the classic 2.5-D stencil): every input plane is staged ONCE per workgroup into LDS as a (kTY + 2) x (kTZ + 2) tile
-// of log values -- rows of 34 consecutive z, i.e. coalesced 136-byte (34-byte for the 8-bit volume) runs; the LUT is applied
+// of log values -- rows of 66 consecutive z, i.e. coalesced 264-byte (66-byte for the 8-bit volume) runs; the LUT is applied
 // while staging, one look-up per staged voxel instead of 27 per output -- each thread then reads its 3 x 3 neighbourhood of
 // the new plane from LDS (9 reads per output instead of 27 loads) and keeps the two previous planes in registers.  The
 // plane buffer is double-buffered: one barrier per plane, and the next plane's global loads are in flight during the
-// arithmetic of the current one.  Results are written as 512-byte (256-byte int16) runs along z.
+// arithmetic of the current one.  Results are written as 1 KiB (512-byte int16) runs along z, one row per wavefront.
+//
+// Tile shape (rows x z, 256 threads unless noted; MI355X, 512^3 float / 512^3 fixed-point / 1024^3 LUT, ms): 8 x 32 0.735 / 0.556 /
+// 4.6; 8 x 64 (512 threads) 0.69 / 0.51 / 4.7; 8 x 128 (1024) 0.74 / 0.60 / 4.85; 4 x 128 (512) 0.69 / 0.556 / 4.75; 6 x 64 (384)
+// 0.89 / 0.64 / 5.5; **4 x 64 0.675 / 0.487 / 4.65** -- the field is dense, its rows are not line-aligned (see the row shift below), so
+// the longer a wavefront's run the fewer lines it shares with another workgroup; that beats the larger halo (1.5 x 1.03 instead of
+// 1.25 x 1.06).  16 or 64 planes per workgroup instead of 32: slower (0.75 / 0.55 / 5.2, 0.755 / 0.54 / 4.8).
 //
 // The arithmetic is the per-voxel kernel's, term for term: three independent fma chains in ascending stamp index
 // (i major, k minor), zero coefficients skipped (image_util.cpp:401-411), IEEE division by 812 * 256; the integer family
@@ -159,7 +165,16 @@ __global__ __launch_bounds__(256) void k_scene_build(const LogSrc lg, const TrSr
 // The field scan the engine needs for its proven rounds and the prescale flag (engine_field_absmax: max |channel|, max
 // squared gradient length, smallest non-zero magnitude) is fused in: each workgroup reduces its voxels and writes five
 // words; k_absmax_reduce folds them.  (Atomics on five addresses from 16 384 workgroups would serialise, see k_ray_bounds.)
-constexpr int kTY = 8, kTZ = 32, kXS = 32;              // output tile of a workgroup: kXS x kTY x kTZ voxels (x walked)
+#ifndef VRT_SCENE_TY
+#define VRT_SCENE_TY 4
+#endif
+#ifndef VRT_SCENE_TZ
+#define VRT_SCENE_TZ 64
+#endif
+#ifndef VRT_SCENE_XS
+#define VRT_SCENE_XS 32
+#endif
+constexpr int kTY = VRT_SCENE_TY, kTZ = VRT_SCENE_TZ, kXS = VRT_SCENE_XS;   // output tile of a workgroup: kXS x kTY x kTZ voxels (x walked)
 constexpr int kZS = 3;                                  // largest row shift (voxels) of a tile: runs aligned to four voxels
 
 template <typename LogSrc, typename TrSrc, typename VoxT>
@@ -172,6 +187,7 @@ __global__ __launch_bounds__(kTY * kTZ) void k_scene_build_tiled(const LogSrc lg
     constexpr bool kFloat = sizeof(VoxT) == 16;
     using T = std::conditional_t<kFloat, float, uint32_t>;   // log values: float, or int32 held as uint32 (the sums wrap)
     constexpr int PY = kTY + 2, PZ = kTZ + 2 + kZS, kThreads = kTY * kTZ;
+    static_assert(PY * PZ <= 2 * kThreads && kThreads <= 1024 && kThreads % 64 == 0, "two staging slots per thread must cover the tile");
     __shared__ T plane[2][PY][PZ];
     __shared__ uint32_t tab_lg[LogSrc::kLut ? 256 : 1], tab_tr[TrSrc::kLut ? 256 : 1];   // LUT scenes: the two tables, one look-up per staged voxel
     if constexpr (LogSrc::kLut) { for (uint32_t k = threadIdx.x; k < 256u; k += kThreads) tab_lg[k] = lg.table_bits(k); }
