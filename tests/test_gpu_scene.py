@@ -136,11 +136,13 @@ def test_replay_reference_dump_files(golden_dir, capsys):
 
 
 @pytest.mark.parametrize("kind", ["f32", "f32_lut", "u32", "u32_lut"])
-@pytest.mark.parametrize("dims", [(3, 3, 3), (9, 11, 35), (37, 10, 70), (41, 36, 33)])
+# the last three extents have (Ny - 2) * (Nz - 2) a multiple of four with field rows that are not: the tiled build then shifts each
+# row's runs by (y * row) & 3 voxels (all four shifts with 33-voxel rows; two and three tiles per row with 70 and 129)
+@pytest.mark.parametrize("dims", [(3, 3, 3), (9, 11, 35), (37, 10, 70), (41, 36, 33), (12, 10, 35), (5, 8, 72), (6, 10, 131)])
 def test_scene_build_field_bits(monkeypatch, kind, dims):
     """Row f-1: the field the scene build leaves in HBM, voxel for voxel, against the oracle's scene build (which is
     pinned to the reference's, tests/test_oracle_vs_reference.py) -- for the LDS-tiled kernel (default) and the
-    per-voxel kernel of round 2, at extents that are not multiples of the tile (8 x 32 outputs, 32 planes per workgroup),
+    per-voxel kernel of round 2, at extents that are not multiples of the tile (4 x 64 outputs, 32 planes per workgroup),
     for array and LUT sources of both families.  The field scan fused into the tiled kernel must give the numbers of the
     separate scan."""
     rng = np.random.RandomState(hash((kind,) + dims) % (2 ** 31))
