@@ -66,10 +66,10 @@ def main():
     rj = json.load(open(rj_path)) if os.path.exists(rj_path) else {}
     if march and "SQ_INSTS_VALU" in pmc[march[0]]:
         m = pmc[march[0]]
-        # the schedule is the kernel's last template argument (SCHED 0 / 1 / 2 = vrt_options.schedule 1 / 2 / 3): bench.py uses the
-        # counters only when the launch it timed ran the same one (vrt_engine_last_schedule)
+        # the schedule is the kernel's SCHED template argument (0 / 1 / 2 = vrt_options.schedule 1 / 2 / 3; the last argument until
+        # the FAST flag followed it): bench.py uses the counters only when the launch it timed ran the same one (vrt_engine_last_schedule)
         import re
-        msch = re.search(r",\s*(\d)\s*>", march[0])
+        msch = re.search(r",\s*(\d)\s*(?:,\s*(?:true|false)\s*)?>", march[0])
         entry = {"kernel": march[0], "round": rnd, "profile": "profiles/" + prof_name,
                  "schedule": (int(msch.group(1)) + 1) if msch else None,
                  "ray_steps": (bench_line or {}).get("config", {}).get("ray_steps_per_gpu"),
