@@ -85,13 +85,64 @@ def make_case(rng, big=False):
     return B, d, tc, sp, sd, inv, iters, opts, fdt, ddt
 
 
+def scene_cases(rng, seconds, seed):
+    """--scenes: random volume extents (1 .. 140 output voxels per axis, so that every row shift, partial tiles and partial
+    slabs occur), array and LUT sources of both families; the field the tiled scene build leaves in HBM must equal the
+    oracle's scene build bit for bit (or both must refuse the scene)."""
+    t0, cases, fails, vox = time.time(), 0, 0, 0
+    while time.time() - t0 < seconds:
+        dims = [int(rng.randint(3, 40)), int(rng.randint(3, 80)), int(rng.randint(3, 143))]
+        if rng.rand() < 0.3:
+            rng.shuffle(dims)
+        kind = str(rng.choice(["f32", "f32_lut", "u32", "u32_lut"]))
+        nvox = dims[0] * dims[1] * dims[2]
+        is_f = kind.startswith("f32")
+        lut_ior = (1.0 + rng.rand(256) * 0.8).astype(np.float32) if is_f else np.round((1.0 + rng.rand(256) * 0.8) * 65536).astype(np.uint32)
+        lut_tr = np.where(rng.rand(256) < 0.8, 0xFFFFFFFF, rng.randint(0, 2 ** 31, 256)).astype(np.uint32)
+        dens = None
+        if kind.endswith("lut"):
+            dens = np.clip(np.cumsum(rng.randint(-1, 2, nvox)), 0, 255).astype(np.uint8)
+            ior, tr = lut_ior[dens], lut_tr[dens]
+        else:
+            base = 1.0 + 0.3 * rng.rand(nvox)
+            ior = base.astype(np.float32) if is_f else np.round(base * 65536).astype(np.uint32)
+            tr = np.where(rng.rand(nvox) < 0.9, 0xFFFFFFFF, rng.randint(0, 2 ** 31, nvox)).astype(np.uint32)
+        bad = []
+        try:
+            hx, hy, hz, tc, _ = oracle.port.scene_build(list(dims), ior, tr)
+            want = np.asarray(oracle.port.interleave(hx, hy, hz, tc))
+        except Exception:                                   # noqa: BLE001  (the oracle raises what the reference throws)
+            want = None
+        try:
+            sc = capi.Scene.from_lut(list(dims), dens, lut_ior, lut_tr) if dens is not None else capi.Scene(list(dims), ior, tr)
+            with sc:
+                got = sc.engine().download_field()
+            if want is None:
+                bad.append("the oracle refuses the scene, the GPU builds it")
+            elif not np.array_equal(got.reshape(-1).view(np.uint8), want.reshape(-1).view(np.uint8)):
+                bad.append("field differs")
+        except capi.VrtError as e:
+            if want is not None:
+                bad.append("exception %r" % (e,))
+        cases += 1
+        vox += nvox
+        if bad:
+            fails += 1
+            print("FAIL scene %d: %s dims=%s kind=%s" % (cases, bad, dims, kind), flush=True)
+    print("scene fuzz: %d scenes, %d failures, %.3g voxels checked in %.0f s (seed %d)" % (cases, fails, vox, time.time() - t0, seed))
+    sys.exit(1 if fails else 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--big", action="store_true", help="fields of 40..140 voxels per axis, 4096..60000 rays, long marches")
+    ap.add_argument("--scenes", action="store_true", help="fuzz the scene build (row f-1) instead of the march")
     args = ap.parse_args()
     rng = np.random.RandomState(args.seed)
+    if args.scenes:
+        scene_cases(rng, args.seconds, args.seed)
     t0, cases, fails, steps = time.time(), 0, 0, 0
     while time.time() - t0 < args.seconds:
         state = rng.get_state()[1][:4].tolist()
